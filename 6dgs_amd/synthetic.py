@@ -1,0 +1,154 @@
+"""Deterministic synthetic inputs for the 6DGS pose path (numpy only, no torch RNG).
+
+Everything the parity fixtures, the tests and ``bench.py`` feed to the path comes from
+here so that the golden generator (which runs the reference in the build container)
+and the GPU box see bit-identical inputs.  Distributions follow SURVEY.md §8(d):
+
+* Gaussians: ``xyz ~ N(0, I3)``, ``scale = 0.005 + 0.05 U(0,1)`` per axis (stored as
+  log, the 3DGS convention, reference ``scene/gaussian_model.py:125-127``),
+  ``rot ~ N(0, I4)`` (normalised on use, ``gaussian_model.py:129-131``),
+  ``f_dc ~ 0.3 N``, ``f_rest ~ 0.05 N`` (16 SH coefficients x 3 channels).
+* Scorer weights: the shapes of ``id_module.th["model_state_dict"]`` with
+  PyTorch-default-like initialisation (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for Linear
+  / Conv, Xavier-uniform + zero bias for q_proj/k_proj as
+  ``our_multihead_attention.py:62-68`` does).
+* Image tokens: ``N(0,1)`` [T, 398] when the backbone is excluded.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+
+F32 = np.float32
+
+
+def make_scene(n: int, seed: int = 0, sh_degree: int = 3, scale_lo: float = 0.005,
+               scale_span: float = 0.05) -> Dict[str, np.ndarray]:
+    """Synthetic 3DGS scene as the raw (pre-activation) parameter arrays."""
+    rng = np.random.default_rng(seed)
+    xyz = rng.standard_normal((n, 3)).astype(F32)
+    scale = (scale_lo + scale_span * rng.random((n, 3))).astype(F32)
+    log_scale = np.log(scale).astype(F32)
+    rot = rng.standard_normal((n, 4)).astype(F32)
+    n_rest = (sh_degree + 1) ** 2 - 1
+    f_dc = (0.3 * rng.standard_normal((n, 1, 3))).astype(F32)
+    f_rest = (0.05 * rng.standard_normal((n, n_rest, 3))).astype(F32)
+    opacity = rng.standard_normal((n, 1)).astype(F32)
+    return {
+        "xyz": xyz,
+        "log_scale": log_scale,
+        "rot": rot,
+        "f_dc": f_dc,
+        "f_rest": f_rest,
+        "opacity": opacity,
+        "sh_degree": np.int64(sh_degree),
+    }
+
+
+def _uniform(rng, shape, bound):
+    return ((rng.random(shape) * 2.0 - 1.0) * bound).astype(F32)
+
+
+def _linear(rng, out_f, in_f):
+    b = 1.0 / math.sqrt(in_f)
+    return _uniform(rng, (out_f, in_f), b), _uniform(rng, (out_f,), b)
+
+
+def _xavier(rng, out_f, in_f):
+    b = math.sqrt(6.0 / (in_f + out_f))
+    return _uniform(rng, (out_f, in_f), b), np.zeros((out_f,), F32)
+
+
+def _conv(rng, ch, k):
+    b = 1.0 / math.sqrt(ch * k * k)
+    return _uniform(rng, (ch, ch, k, k), b), _uniform(rng, (ch,), b)
+
+
+def make_scorer_state_dict(seed: int = 0, with_cnn: bool = False) -> Dict[str, np.ndarray]:
+    """State dict with the key names/shapes of the reference ``IdentificationModule``
+    (``identification_module.py:13-46``; keys listed in SURVEY.md §8(b))."""
+    rng = np.random.default_rng(1000 + seed)
+    sd: Dict[str, np.ndarray] = {}
+    for name, (o, i) in (
+        ("ray_preprocessor.mlp.0", (512, 141)),
+        ("ray_preprocessor.mlp.2", (512, 512)),
+        ("ray_preprocessor.mlp2.0", (512, 653)),
+        ("ray_preprocessor.mlp2.2", (384, 512)),
+    ):
+        w, b = _linear(rng, o, i)
+        sd[name + ".weight"], sd[name + ".bias"] = w, b
+    for name, (o, i) in (("attention.q_proj", (384, 398)), ("attention.k_proj", (384, 384))):
+        w, b = _xavier(rng, o, i)
+        sd[name + ".weight"], sd[name + ".bias"] = w, b
+    if with_cnn:
+        rng2 = np.random.default_rng(2000 + seed)
+        for name, k in (
+            ("camera_direction_prediction_network.dim_reducer1.0", 5),
+            ("camera_direction_prediction_network.dim_reducer1.2", 5),
+            ("camera_direction_prediction_network.dim_reducer1.4", 5),
+            ("camera_direction_prediction_network.dim_reducer2.0", 4),
+        ):
+            w, b = _conv(rng2, 384, k)
+            sd[name + ".weight"], sd[name + ".bias"] = w, b
+        for name, (o, i) in (
+            ("camera_direction_prediction_network.mlp.0", (256, 384)),
+            ("camera_direction_prediction_network.mlp.2", (3, 256)),
+        ):
+            w, b = _linear(rng2, o, i)
+            sd[name + ".weight"], sd[name + ".bias"] = w, b
+        sd["backbone_wrapper.norm_mean"] = np.array([0.485, 0.456, 0.406], F32)
+        sd["backbone_wrapper.norm_std"] = np.array([0.229, 0.224, 0.225], F32)
+    return sd
+
+
+def make_tokens(t: int, seed: int = 0, scale: float = 1.0, dim: int = 398) -> np.ndarray:
+    """Stand-in for ``features_img_w_pe_flat`` [T, 398] (``backbone.py:110-114``)."""
+    rng = np.random.default_rng(3000 + seed)
+    return (scale * rng.standard_normal((t, dim))).astype(F32)
+
+
+def make_rays(r: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Free-standing ray set (origins ~ N(0,1), unit directions, rgb in [0,1.2))."""
+    rng = np.random.default_rng(4000 + seed)
+    ori = rng.standard_normal((r, 3)).astype(F32)
+    d = rng.standard_normal((r, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    rgb = (1.2 * rng.random((r, 3))).astype(F32)
+    return {"ori": ori, "dir": d.astype(F32), "rgb": rgb}
+
+
+def random_rotation(rng) -> np.ndarray:
+    q, r = np.linalg.qr(rng.standard_normal((3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def make_cameras(b: int, seed: int = 0, width: int = 800, height: int = 800, fov: float = 0.8,
+                 rgba: bool = False):
+    """``b`` synthetic query views: random rotation, T=(0,0,4), uint8 U{0..255} image.
+    Returned as plain dicts with the ``CameraInfo`` field names (``scene_structure.py:7-17``)."""
+    rng = np.random.default_rng(5000 + seed)
+    cams = []
+    for i in range(b):
+        rot = random_rotation(rng)
+        ch = 4 if rgba else 3
+        img = rng.integers(0, 256, size=(height, width, ch), dtype=np.uint8)
+        cams.append({
+            "uid": i, "R": rot.astype(np.float64), "T": np.array([0.0, 0.0, 4.0]),
+            "FovY": fov, "FovX": fov, "image": img, "image_path": "", "image_name": f"syn_{i}",
+            "width": width, "height": height,
+        })
+    return cams
+
+
+def checksum(sd: Dict[str, np.ndarray]) -> float:
+    """Order-stable float64 checksum of a dict of arrays (guards against RNG stream drift)."""
+    tot = 0.0
+    for k in sorted(sd):
+        a = np.asarray(sd[k], dtype=np.float64).ravel()
+        tot += float(np.dot(a, np.cos(np.arange(a.size, dtype=np.float64) * 1e-3)))
+    return tot

@@ -1,0 +1,221 @@
+"""Pins the CPU oracle (oracle/sixdgs_oracle.c) against golden vectors produced by the reference
+(oracle/gen_golden.py, run in the build container).  One test per SURVEY.md §8(a) row.
+
+Tolerances: the oracle restates the reference's fp32 operation order, but libm's sinf/cosf/powf
+differ from torch's SLEEF kernels by <=1 ulp and BLAS summation order is unspecified, so float
+results are compared at ~1e-6 relative; integer/boolean/index results must be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+
+def test_a1_rotation_matrices(oracle, golden):
+    g = golden("g1_quadricell")
+    assert rel_err(oracle.build_rotation(g["rot"]), g["rotmat"]) < 1e-6
+
+
+def test_a2_mask_degraded(oracle, golden):
+    g = golden("g1_quadricell")
+    m = oracle.mask_degraded(g["a2_scale"])
+    assert 0.0 < g["a2_mask"].mean() < 1.0          # both outcomes present
+    assert (m == g["a2_mask"]).all()
+
+
+@pytest.mark.parametrize("P", [50, 64, 256])
+def test_a6_quadricell_centers(oracle, golden, P):
+    g = golden("g1_quadricell")
+    pts, eid = oracle.quadricell_centers(g["scale"], P)
+    ref = g[f"P{P}_points"]
+    assert pts.shape == ref.shape
+    assert (eid == g[f"P{P}_eid"]).all()            # ragged structure identical
+    d = np.abs(pts - ref).max(1)
+    # z (ring centre) has no transcendental: exact
+    assert np.abs(pts[:, 2] - ref[:, 2]).max() < 1e-7
+    # arc-length lookup: a cell whose theta is within an ulp of a table entry may pick the
+    # neighbouring entry (one table step ~ 2*pi/999 rad).  Documented tie policy: <=0.2 % of cells.
+    flips = d > 1e-6
+    assert flips.mean() <= 2e-3, flips.sum()
+    scale_max = g["scale"][eid].max(1)
+    assert (d[flips] <= 2.5 * (2 * np.pi / 999) * scale_max[flips]).all()
+
+
+@pytest.mark.parametrize("P", [50, 64, 256])
+def test_a7_mask_and_compute_rays(oracle, golden, P):
+    g = golden("g1_quadricell")
+    ori, dr, mid = oracle.mask_and_compute_rays(g[f"P{P}_points"], g[f"P{P}_eid"], g["normals"], g["xyz"], g["rotmat"])
+    assert (mid == g[f"P{P}_mid"]).all()
+    assert np.abs(ori - g[f"P{P}_ori"]).max() < 1e-6
+    assert np.abs(dr - g[f"P{P}_dir"]).max() < 1e-6
+    # the literal mask is normal.x * p_world.x > 0 (outer-product [0,0] entry), NOT the dot product
+    Rm = g["rotmat"][g[f"P{P}_eid"]]
+    pw = np.einsum("nij,nj->ni", Rm, g[f"P{P}_points"])
+    dot_mask = (g["normals"][g[f"P{P}_eid"]] * pw).sum(1) > 0
+    assert dot_mask.sum() != mid.shape[0] or not (np.nonzero(dot_mask)[0].shape[0] == mid.shape[0])
+
+
+def test_a4_normals(oracle, golden):
+    g = golden("g2_normals")
+    n, knn = oracle.compute_normals(g["pts"], g["pts"], 20, return_knn=True)
+    same = np.array([set(a) == set(b) for a, b in zip(knn, g["knn"])])
+    assert same.mean() > 0.99
+    dots = (n * g["normals"]).sum(1)
+    assert (dots[same] > 0.9999).all()
+    assert np.abs(n[same] - g["normals"][same]).max() < 5e-4
+
+
+def test_a5_sym_eig(oracle, golden):
+    g = golden("g2_normals")
+    mats = g["mats"]
+    vals, vecs = oracle.sym_eig_3x3(mats)
+    nspd = 200
+    scale = np.abs(g["eigvals"][:nspd]).max(1, keepdims=True)
+    assert (np.abs(vals[:nspd] - g["eigvals"][:nspd]) / scale).max() < 2e-5
+    # eigenvectors: compare where the spectrum is well separated
+    ev = g["eigvals"][:nspd]
+    gap = np.minimum(ev[:, 1] - ev[:, 0], ev[:, 2] - ev[:, 1]) / scale[:, 0]
+    ok = gap > 1e-2
+    assert ok.sum() > 150
+    assert np.abs(vecs[:nspd][ok] - g["eigvecs"][:nspd][ok]).max() < 2e-3
+    # diagonal inputs
+    assert np.abs(vals[200:208] - g["eigvals"][200:208]).max() < 1e-4
+    # repeated eigenvalues: acos is ill-conditioned at r=+-1 -> check invariants instead of parity
+    for i in range(208, mats.shape[0]):
+        A = mats[i].astype(np.float64)
+        lam_true = np.linalg.eigvalsh(A)
+        assert np.abs(np.sort(vals[i]) - lam_true).max() < 2e-3 * np.abs(lam_true).max()
+        assert np.abs(np.sort(g["eigvals"][i]) - lam_true).max() < 2e-3 * np.abs(lam_true).max()
+
+
+@pytest.mark.parametrize("tgt,n0", [(35, 3), (64, 1), (256, 1), (50, 1)])
+def test_a8_isocell_distribution(oracle, golden, tgt, n0):
+    g = golden("g3_isocell")
+    d = oracle.isocell_distribution(tgt, n0)
+    ref = g[f"dirs_{tgt}_{n0}"]
+    assert d.shape == ref.shape
+    assert np.abs(d - ref).max() < 5e-7
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("tgt", [64, 256])
+def test_a9_rotate_isocell(oracle, golden, tgt):
+    g = golden("g3_isocell")
+    r = oracle.rotate_isocell(g[f"dirs_{tgt}_1"], g["normals"])
+    ref = g[f"rot_{tgt}"]
+    assert (np.isnan(r) == np.isnan(ref)).all()      # normal || z -> NaN, as the reference
+    assert np.isnan(ref[0]).all() and np.isnan(ref[2]).all()
+    assert np.nanmax(np.abs(r - ref)) < 1e-6
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_a10_sh_colour(oracle, golden, deg):
+    g = golden("g4_sh")
+    c = oracle.eval_sh_color(g["sh"], g["dir"], deg)
+    assert np.abs(c - g[f"rgb_deg{deg}"]).max() < 1e-6
+    assert (c >= 0).all() and (c == 0).any()         # clamp_min exercised
+
+
+@pytest.fixture(scope="module")
+def scorer_state(oracle, golden, syn):
+    g = golden("g5_scorer")
+    sd = syn.make_scorer_state_dict(0)
+    assert syn.checksum(sd) == float(g["sd_checksum"]), "numpy RNG stream drifted from the fixture"
+    rays = syn.make_rays(4096, 0)
+    feat, key = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
+    return g, sd, rays, feat, key
+
+
+def test_a12_positional_encoding(oracle, scorer_state):
+    g, sd, rays, _, _ = scorer_state
+    x = oracle.ray_input(rays["ori"][:16], rays["dir"][:16], rays["rgb"][:16])
+    assert np.abs(x[:, 9:9 + 48] - g["pe_pts16"]).max() < 2e-7
+    assert (x[:, :3] == rays["ori"][:16]).all()
+
+
+def test_a13_ray_features_and_keys(scorer_state):
+    g, sd, rays, feat, key = scorer_state
+    assert rel_err(feat[:128], g["feat_head"]) < 5e-6
+    assert rel_err(key[:128], g["key_head"]) < 5e-6
+    assert rel_err(feat.astype(np.float64).sum(0), g["feat_sum"]) < 1e-6
+    assert rel_err(key.astype(np.float64).sum(0), g["key_sum"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,T,scale", [("flat256", 256, 1.0), ("peaky256", 256, 40.0), ("peaky137", 137, 40.0),
+                                         ("mid1", 1, 10.0)])
+def test_a14_a15_scores_topk(oracle, scorer_state, syn, tag, T, scale):
+    g, sd, rays, feat, key = scorer_state
+    q = oracle.q_proj(syn.make_tokens(T, 1, scale), sd)
+    assert rel_err(q[:8], g[f"{tag}_q_head"]) < 5e-6
+    s, mx, sm = oracle.attention_scores(q, key, return_stats=True)
+    assert rel_err(s, g[f"{tag}_scores"]) < 1e-5
+    assert abs(float(s.astype(np.float64).sum()) - T) < 1e-3 * T     # softmax rows sum to 1
+    assert np.abs(mx - g[f"{tag}_rowmax"]).max() < 1e-4
+    idx, val = oracle.topk(s, 100)
+    assert rel_err(val, g[f"{tag}_val"]) < 1e-5
+    # near-tie policy: the index SET must match wherever the fp64 gap to the 101st value exceeds
+    # 4x the fp32 error bound; on these fixtures that holds for every member.
+    s64 = g[f"{tag}_scores64"]
+    order = np.argsort(-s64)
+    thr = s64[order[100]]
+    err = 4 * 1e-6 * s64[order[0]]
+    must = set(order[:100][s64[order[:100]] - thr > err].tolist())
+    assert must <= set(idx.tolist())
+    assert set(idx.tolist()) == set(g[f"{tag}_idx"].tolist())
+    assert (idx == g[f"{tag}_idx"]).all()
+
+
+def test_topk_tie_rule(oracle):
+    s = np.array([1, 3, 3, 2, 3, 0, 2], np.float32)
+    idx, val = oracle.topk(s, 4)
+    assert idx.tolist() == [1, 2, 4, 3] and val.tolist() == [3, 3, 3, 2]
+
+
+def _cases(g):
+    return [str(c) for c in g["cases"]]
+
+
+def test_a17_to_a21_pose_tail(oracle, golden):
+    g = golden("g6_pose")
+    seen_nan = False
+    for name in _cases(g):
+        r = oracle.pose_from_topk(g[f"{name}_ori"], g[f"{name}_dir"], g[f"{name}_idx"], g[f"{name}_w"], g[f"{name}_up"])
+        assert (r["keep"] == g[f"{name}_keep_mask"]).all(), name
+        assert (r["flags"] == g[f"{name}_flags"]).all(), name
+        assert np.abs(r["c2w"] - g[f"{name}_c2w"]).max() < 1e-5, name
+        if np.isnan(g[f"{name}_centre"]).any():
+            seen_nan = True
+            assert np.isnan(r["centre"]).all()
+            assert (r["c2w"] == np.eye(4, dtype=np.float32)).all()     # test.py:216-218
+        else:
+            assert np.abs(r["centre"] - g[f"{name}_centre"]).max() < 1e-5, name
+            assert np.abs(r["w_final"][r["keep"]] - g[f"{name}_w_final"]).max() < 1e-7, name
+        te, ae = oracle.pose_errors(g[f"{name}_gt"], r["c2w"])
+        assert abs(te - float(g[f"{name}_terr"])) < 1e-5, name
+        assert abs(ae - float(g[f"{name}_aerr"])) < 1e-3, name
+    assert seen_nan
+    # filter edge cases really exercised
+    assert g["dups_keep_mask"].sum() < 100 and g["few5_keep_mask"].sum() == 5 and g["few8_keep_mask"].sum() == 20
+
+
+def test_a20_make_rotation_mat(oracle, golden):
+    g = golden("g6_pose")
+    for i, (d, u, ref) in enumerate(zip(g["rot_dirs"], g["rot_ups"], g["rot_mats"])):
+        m = oracle.make_rotation_mat(d, u)
+        if i < 2:
+            # up == +-direction: cross(up, direction) is exactly 0 here -> NaN axes -> identity pose
+            # (test.py:216-218).  torch's CPU cross kernel contracts a*b - c*d into an FMA, so the
+            # reference returns the rounding residue normalised to a unit vector -- noise, not a
+            # contract; documented deviation for this degenerate input.
+            assert np.isnan(m[:2]).all() and not np.isnan(ref).any()
+            continue
+        assert np.abs(m - ref).max() < 1e-6
+
+
+def test_a18_line_intersection_exact_point(oracle):
+    rng = np.random.default_rng(5)
+    c = np.array([0.3, -1.2, 2.0], np.float32)
+    o = rng.standard_normal((50, 3)).astype(np.float32)
+    d = c[None] - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    assert np.abs(oracle.line_intersection(o, d.astype(np.float32)) - c).max() < 1e-4
