@@ -1,0 +1,211 @@
+"""BackboneWrapper -- mirror of pose_estimation/backbone.py:34-139: resize 256 (bicubic, antialias)
+-> centre crop 224 -> ImageNet normalisation -> DINOv2 ViT-S/14 patch tokens [256,384] + 14-channel
+grid position encoding -> tokens [T<=256, 398], selected by the alpha mask.
+
+Stays on PyTorch-ROCm (frozen third-party ViT): its output is the Q-side INPUT of
+the HIP boundary.  torchvision is not required: its tensor Resize/CenterCrop are F.interpolate
+(antialias) and a slice, reproduced here.
+
+DINOv2 weights come from torch.hub in the reference (backbone.py:15, network access).  Offline the
+factory falls back to a randomly initialised ViT-S/14 of the same architecture (module names follow
+the dinov2 state_dict so real weights load when available); pass `backbone=` to inject your own
+module exposing forward_features(x)["x_norm_patchtokens"].
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+# ---- minimal ViT-S/14 with dinov2's parameter names ------------------------------------------------
+class _Attention(torch.nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = torch.nn.Linear(dim, dim * 3)
+        self.proj = torch.nn.Linear(dim, dim)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+        y = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(y.transpose(1, 2).reshape(b, n, c))
+
+
+class _LayerScale(torch.nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = torch.nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class _Mlp(torch.nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(dim, hidden)
+        self.fc2 = torch.nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _Block(torch.nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = torch.nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, heads)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = torch.nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, dim * 4)
+        self.ls2 = _LayerScale(dim)
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class _PatchEmbed(torch.nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = torch.nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class ViTS14(torch.nn.Module):
+    """DINOv2 ViT-S/14 forward (no register tokens), 224x224 -> 256 patch tokens of width 384."""
+
+    def __init__(self, dim=384, depth=12, heads=6, patch=14, pos_grid=37):
+        super().__init__()
+        self.patch_size = patch
+        self.patch_embed = _PatchEmbed(dim, patch)
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = torch.nn.Parameter(torch.zeros(1, 1 + pos_grid * pos_grid, dim))
+        self.mask_token = torch.nn.Parameter(torch.zeros(1, dim))
+        self.blocks = torch.nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
+        self.norm = torch.nn.LayerNorm(dim, eps=1e-6)
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            self.pos_embed.copy_(0.02 * torch.randn(self.pos_embed.shape, generator=g))
+            self.cls_token.copy_(1e-6 * torch.randn(self.cls_token.shape, generator=g))
+
+    def _pos(self, n_side):
+        pe = self.pos_embed
+        m = int(math.isqrt(pe.shape[1] - 1))
+        if m == n_side:
+            return pe
+        patch = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
+        patch = F.interpolate(patch, size=(n_side, n_side), mode="bicubic", align_corners=False)
+        return torch.cat([pe[:, :1], patch.permute(0, 2, 3, 1).reshape(1, n_side * n_side, -1)], dim=1)
+
+    def forward_features(self, x):
+        b = x.shape[0]
+        t = self.patch_embed(x)
+        t = torch.cat([self.cls_token.expand(b, -1, -1), t], dim=1) + self._pos(x.shape[-1] // self.patch_size)
+        for blk in self.blocks:
+            t = blk(t)
+        t = self.norm(t)
+        return {"x_norm_clstoken": t[:, 0], "x_norm_patchtokens": t[:, 1:]}
+
+
+def create_backbone(type="dino", backbone: Optional[torch.nn.Module] = None, **kwargs):
+    """(model, wh, num_features) as backbone.py:6-22."""
+    if type != "dino":
+        raise NotImplementedError("only the 'dino' backbone is on the accelerated path (reference default, "
+                                  "pretrain_eval_attention.py:54)")
+    if backbone is None:
+        try:
+            backbone = torch.hub.load("facebookresearch/dinov2", "dinov2_vits14")
+        except Exception as e:  # offline: no network, no cache
+            warnings.warn(f"DINOv2 weights unavailable ({type(e).__name__}); using a randomly initialised ViT-S/14")
+            backbone = ViTS14()
+    return backbone, (16, 16), 384
+
+
+def _resize_short_side(x, size, mode):
+    h, w = x.shape[-2:]
+    if h <= w:
+        nh, nw = size, int(size * w / h)
+    else:
+        nh, nw = int(size * h / w), size
+    if (nh, nw) == (h, w):
+        return x
+    return F.interpolate(x, size=(nh, nw), mode=mode, align_corners=False, antialias=True)
+
+
+def _center_crop(x, size):
+    h, w = x.shape[-2:]
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return x[..., top:top + size, left:left + size]
+
+
+class BackboneWrapper(torch.nn.Module):
+    def __init__(self, backbone_type: str = "dino", backbone: Optional[torch.nn.Module] = None) -> None:
+        super().__init__()
+        assert backbone_type in ["dino", "superpoint"]
+        self.image_preprocessing_net, backbone_wh, img_num_features = create_backbone(type=backbone_type, backbone=backbone)
+        self.norm_mean = torch.nn.Parameter(torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=torch.float32), requires_grad=False)
+        self.norm_std = torch.nn.Parameter(torch.tensor(IMAGENET_DEFAULT_STD, dtype=torch.float32), requires_grad=False)
+        self.backbone_wh = backbone_wh
+        self.img_num_features = img_num_features
+        self._pe_cache = {}
+
+    # -- the two transform pipelines of backbone.py:52-77 ----------------------------------------------
+    def transformations(self, x):
+        x = _center_crop(_resize_short_side(x, 256, "bicubic"), 224)
+        mean = torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_DEFAULT_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+        return (x - mean) / std
+
+    def mask_transformations(self, m):
+        m = _center_crop(_resize_short_side(m, 256, "bilinear"), 224)
+        return F.interpolate(m, size=(self.backbone_wh[0], self.backbone_wh[0]), mode="bilinear", align_corners=False,
+                             antialias=True)
+
+    def preprocess(self, img, mask):
+        """img [H,W,3] fp32, mask [H,W] bool -> (norm_img [1,3,224,224], token mask [16,16] bool)"""
+        norm_img = self.transformations(img[None].permute(0, 3, 1, 2))
+        mask_img = self.mask_transformations(mask[None, None] * 1.0)[0, 0] > 0.1
+        return norm_img, mask_img
+
+    def position_encoding(self, dtype, device):
+        key = (dtype, str(device))
+        if key not in self._pe_cache:
+            self._pe_cache[key] = self.get_img_position_encoding(self.backbone_wh, 3, dtype=dtype, device=device)
+        return self._pe_cache[key]
+
+    def features_from_norm(self, norm_imgs):
+        """[B,3,224,224] -> patch tokens [B,16,16,384]"""
+        tok = self.image_preprocessing_net.forward_features(norm_imgs)["x_norm_patchtokens"]
+        return tok.reshape(tok.shape[0], self.backbone_wh[0], self.backbone_wh[1], self.img_num_features)
+
+    def assemble(self, feat_hw, mask_img):
+        """one image: feat_hw [16,16,384], mask [16,16] -> (tokens+pe [T,398], tokens [T,384], fmap [384,16,16])"""
+        pe = self.position_encoding(feat_hw.dtype, feat_hw.device)
+        with_pe = torch.cat([feat_hw, pe], dim=-1)
+        return with_pe[mask_img].view(-1, with_pe.shape[-1]), feat_hw[mask_img].view(-1, feat_hw.shape[-1]), feat_hw.permute(2, 0, 1)
+
+    def forward(self, img, mask):
+        norm_img, mask_img = self.preprocess(img, mask)
+        feat = self.features_from_norm(norm_img)[0]
+        return self.assemble(feat, mask_img)
+
+    @staticmethod
+    def get_img_position_encoding(img_features_shape, freqs, dtype=torch.float32, device="cpu"):
+        """backbone.py:116-139: [pos(2), sin(2*freqs), cos(2*freqs)] on linspace(-1,1)^2."""
+        grids = [torch.linspace(-1.0, 1.0, steps=s, dtype=dtype, device=device) for s in img_features_shape]
+        positions = torch.stack(torch.meshgrid(*grids, indexing="ij"), dim=-1).reshape(-1, len(grids))
+        freq_bands = (2 ** torch.arange(freqs).float()).to(positions.device)
+        pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
+        pts = torch.cat([positions, torch.sin(pts), torch.cos(pts)], dim=-1)
+        return pts.reshape(*img_features_shape, pts.shape[-1])

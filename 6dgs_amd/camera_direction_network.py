@@ -1,0 +1,39 @@
+"""CameraDirectionPredictor -- parameter-compatible mirror of
+pose_estimation/camera_direction_network.py:6-90 (3x Conv5 + Conv4 + MLP 384->256->3 on the 16x16
+DINOv2 feature map).  It stays on PyTorch-ROCm / MIOpen behind the boundary (SURVEY.md §8 a22:
+~1.65 GFLOP per pose, not the bottleneck); module names match the reference's state_dict keys.
+"""
+from __future__ import annotations
+
+from math import prod
+
+import torch
+
+
+class CameraDirectionPredictor(torch.nn.Module):
+    def __init__(self, image_feature_channel=256, image_size=(16, 16), pospe=8, featureC=256, fea_output=3):
+        super().__init__()
+        self.direction_input = 2 * pospe * 3 + 3
+        self.dim_reducer1, size1 = self._reducer(image_size, image_feature_channel, kernel_size=5, num_conv2d=3)
+        self.dim_reducer2, size2 = self._reducer(size1, image_feature_channel, kernel_size=4, num_conv2d=1)
+        self.in_mlpC = prod(size2) * image_feature_channel
+        self.mlp = torch.nn.Sequential(
+            torch.nn.Linear(self.in_mlpC, featureC), torch.nn.ReLU(inplace=True), torch.nn.Linear(featureC, fea_output))
+        self.pospe = pospe
+
+    @staticmethod
+    def _reducer(image_size, ch, kernel_size, num_conv2d):
+        layers = []
+        size = list(image_size)
+        for _ in range(num_conv2d):
+            size = [int(s - kernel_size + 1) for s in size]
+            layers += [torch.nn.Conv2d(ch, ch, kernel_size=kernel_size), torch.nn.ReLU(inplace=True)]
+        return torch.nn.Sequential(*layers), size
+
+    def forward(self, image_features):
+        """image_features [384,16,16] -> [3]   or batched [B,384,16,16] -> [B,3]"""
+        single = image_features.dim() == 3
+        x = image_features[None] if single else image_features
+        x = self.dim_reducer2(self.dim_reducer1(x))
+        y = self.mlp(x.reshape(x.shape[0], -1))
+        return y[0] if single else y

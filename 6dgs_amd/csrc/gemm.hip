@@ -1,0 +1,267 @@
+// gemm.hip -- dense layers of the scorer: ray encoding, the ray MLP + k_proj chain (key cache,
+// once per scene), q_proj (per image), weight packing.  All contractions run on the fp32 MFMA tile
+// kernel of gemm_kernel.h with bias/ReLU fused into the epilogue.
+#include "gemm_kernel.h"
+#include "device_math.h"
+
+using namespace sdg;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// y[M,N] = act(A . W^T + b)
+// ------------------------------------------------------------------------------------------------
+template <int WM, bool RELU>
+__global__ void __launch_bounds__(WM * 128, 2) k_linear(GemmOperands g, const float* __restrict__ bias, float* __restrict__ y,
+                                                         int64_t ldy, unsigned n_tiles, unsigned total_tiles) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * GemmSmem<WM>::kStageFloats];
+  const unsigned w = xcd_remap(blockIdx.x, total_tiles);
+  const int64_t row0 = (int64_t)(w / n_tiles) * (WM * 64);
+  const int64_t col0 = (int64_t)(w % n_tiles) * kBN;
+  f32x16 acc[2][2];
+  gemm_mainloop<WM>(g, row0, col0, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = col0 + acc_col(wn, tn, lane);
+    const float bv = (bias != nullptr && col < g.n) ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + acc_row(wm, tm, r, lane);
+        if (row < g.m && col < g.n) {
+          float v = acc[tm][tn][r] + bv;
+          if (RELU) v = fmaxf(v, 0.f);
+          y[row * ldy + col] = v;
+        }
+      }
+  }
+}
+
+template <int WM>
+int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, hipStream_t s) {
+  const int64_t m_tiles = sdg_cdiv(g.m, WM * 64), n_tiles = sdg_cdiv(g.n, kBN);
+  const int64_t total = m_tiles * n_tiles;
+  if (total <= 0) return 0;
+  if (total > 0x7fffffffLL) return SIXDGS_E_BADARG;
+  if (relu)
+    hipLaunchKernelGGL((k_linear<WM, true>), dim3((unsigned)total), dim3(WM * 128), 0, s, g, bias, y, ldy, (unsigned)n_tiles,
+                       (unsigned)total);
+  else
+    hipLaunchKernelGGL((k_linear<WM, false>), dim3((unsigned)total), dim3(WM * 128), 0, s, g, bias, y, ldy, (unsigned)n_tiles,
+                       (unsigned)total);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12: x[R,144]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ray_encode(const float* __restrict__ ori, const float* __restrict__ dir,
+                                                     const float* __restrict__ rgb, int64_t R, float* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * SIXDGS_RAY_IN_PAD) return;
+  const int64_t ray = i / SIXDGS_RAY_IN_PAD;
+  const int col = (int)(i - ray * SIXDGS_RAY_IN_PAD);
+  const float p[3] = {ori[3 * ray], ori[3 * ray + 1], ori[3 * ray + 2]};
+  const float d[3] = {dir[3 * ray], dir[3 * ray + 1], dir[3 * ray + 2]};
+  const float c[3] = {rgb[3 * ray], rgb[3 * ray + 1], rgb[3 * ray + 2]};
+  x[i] = ray_input_element(p, d, c, col);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: dst[n][kd] = k < ks ? src[n][k] : 0 ;  transposed variant dst[k][n]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pad_rows(const float* __restrict__ src, int n, int ks, int kd, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * kd) return;
+  int r = i / kd, k = i - r * kd;
+  dst[i] = k < ks ? src[(int64_t)r * ks + k] : 0.f;
+}
+__global__ void k_pad_transpose(const float* __restrict__ src, int n, int ks, int kd, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // dst index [k][n]
+  if (i >= n * kd) return;
+  int k = i / n, r = i - k * n;
+  dst[i] = k < ks ? src[(int64_t)r * ks + k] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// q_proj: q[b][t][n] = sum_k tok[b][t][k] wq_t[k][n] + bq[n]; 398-wide token rows are not 16-B
+// aligned, so this small layer (78 MFLOP per image) runs on the VALU from an LDS copy of the rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQTok = 8;
+__global__ void __launch_bounds__(SIXDGS_D) k_q_proj(const float* __restrict__ tokens, const int* __restrict__ n_tok,
+                                                      const float* __restrict__ wq_t, const float* __restrict__ bq,
+                                                      float* __restrict__ q) {
+  __shared__ float tk[kQTok][SIXDGS_TOK_IN + 2];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kQTok;
+  const int nt = n_tok[b];
+  const int n = threadIdx.x;
+  float* qo = q + ((int64_t)b * SIXDGS_MAX_TOKENS + t0) * SIXDGS_D;
+  if (t0 >= nt) {  // rows beyond the image's token count: defined (zero) but never consumed
+    for (int t = 0; t < kQTok; ++t) qo[(int64_t)t * SIXDGS_D + n] = 0.f;
+    return;
+  }
+  const float* src = tokens + ((int64_t)b * SIXDGS_MAX_TOKENS + t0) * SIXDGS_TOK_IN;
+  for (int i = threadIdx.x; i < kQTok * SIXDGS_TOK_IN; i += blockDim.x) {
+    int t = i / SIXDGS_TOK_IN, k = i - t * SIXDGS_TOK_IN;
+    tk[t][k] = (t0 + t < nt) ? src[i] : 0.f;
+  }
+  __syncthreads();
+  float acc[kQTok];
+#pragma unroll
+  for (int t = 0; t < kQTok; ++t) acc[t] = 0.f;
+  for (int k = 0; k < SIXDGS_TOK_IN; ++k) {
+    const float w = wq_t[(int64_t)k * SIXDGS_D + n];
+#pragma unroll
+    for (int t = 0; t < kQTok; ++t) acc[t] = fmaf(tk[t][k], w, acc[t]);
+  }
+  const float bv = bq[n];
+#pragma unroll
+  for (int t = 0; t < kQTok; ++t) qo[(int64_t)t * SIXDGS_D + n] = (t0 + t < nt) ? acc[t] + bv : 0.f;
+}
+
+constexpr size_t pad64(size_t x) { return (x + 63) / 64 * 64; }
+constexpr size_t kOffW1 = 0;
+constexpr size_t kOffB1 = kOffW1 + pad64(512 * 144);
+constexpr size_t kOffW2 = kOffB1 + pad64(512);
+constexpr size_t kOffB2 = kOffW2 + pad64(512 * 512);
+constexpr size_t kOffW3 = kOffB2 + pad64(512);
+constexpr size_t kOffB3 = kOffW3 + pad64(512 * 656);
+constexpr size_t kOffW4 = kOffB3 + pad64(512);
+constexpr size_t kOffB4 = kOffW4 + pad64(384 * 512);
+constexpr size_t kOffWk = kOffB4 + pad64(384);
+constexpr size_t kOffBk = kOffWk + pad64(384 * 384);
+constexpr size_t kOffWq = kOffBk + pad64(384);
+constexpr size_t kOffBq = kOffWq + pad64(400 * 384);
+constexpr size_t kPackedFloats = kOffBq + pad64(384);
+
+constexpr size_t kChunkFloatsPerRay = SIXDGS_RAY_IN_PAD + SIXDGS_HID + SIXDGS_HID;
+
+}  // namespace
+
+extern "C" {
+
+int sixdgs_abi_version(void) { return SIXDGS_ABI_VERSION; }
+
+const char* sixdgs_error_string(int status) {
+  if (status == 0) return "ok";
+  if (status == SIXDGS_E_BADARG) return "sixdgs: bad argument";
+  if (status == SIXDGS_E_WORKSPACE) return "sixdgs: workspace too small";
+  if (status == SIXDGS_E_UNSUPPORTED) return "sixdgs: unsupported configuration";
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "sixdgs: unknown error";
+}
+
+size_t sixdgs_packed_weights_floats(void) { return kPackedFloats; }
+
+int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* mlp2_w, const float* mlp2_b, const float* mlp2_0_w,
+                        const float* mlp2_0_b, const float* mlp2_2_w, const float* mlp2_2_b, const float* kproj_w,
+                        const float* kproj_b, const float* qproj_w, const float* qproj_b, float* packed,
+                        sixdgs_scorer_weights* out, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(mlp0_w && mlp0_b && mlp2_w && mlp2_b && mlp2_0_w && mlp2_0_b && mlp2_2_w && mlp2_2_b && kproj_w && kproj_b &&
+                qproj_w && qproj_b && packed && out);
+  hipStream_t s = sdg_stream(stream);
+  auto pad = [&](const float* src, int n, int ks, int kd, size_t off) {
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)sdg_cdiv((int64_t)n * kd, 256)), dim3(256), 0, s, src, n, ks, kd, packed + off);
+  };
+  pad(mlp0_w, 512, 141, 144, kOffW1);
+  pad(mlp0_b, 1, 512, 512, kOffB1);
+  pad(mlp2_w, 512, 512, 512, kOffW2);
+  pad(mlp2_b, 1, 512, 512, kOffB2);
+  pad(mlp2_0_w, 512, 653, 656, kOffW3);
+  pad(mlp2_0_b, 1, 512, 512, kOffB3);
+  pad(mlp2_2_w, 384, 512, 512, kOffW4);
+  pad(mlp2_2_b, 1, 384, 384, kOffB4);
+  pad(kproj_w, 384, 384, 384, kOffWk);
+  pad(kproj_b, 1, 384, 384, kOffBk);
+  hipLaunchKernelGGL(k_pad_transpose, dim3((unsigned)sdg_cdiv(384 * 400, 256)), dim3(256), 0, s, qproj_w, 384, 398, 400,
+                     packed + kOffWq);
+  pad(qproj_b, 1, 384, 384, kOffBq);
+  SDG_LAUNCH_OK();
+  out->w1 = packed + kOffW1; out->b1 = packed + kOffB1;
+  out->w2 = packed + kOffW2; out->b2 = packed + kOffB2;
+  out->w3 = packed + kOffW3; out->b3 = packed + kOffB3;
+  out->w4 = packed + kOffW4; out->b4 = packed + kOffB4;
+  out->wk = packed + kOffWk; out->bk = packed + kOffBk;
+  out->wq = packed + kOffWq; out->bq = packed + kOffBq;
+  return 0;
+}
+
+int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int64_t r, float* x, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(r >= 0);
+  if (r == 0) return 0;
+  SDG_CHECK_ARG(ori && dir && rgb && x);
+  hipLaunchKernelGGL(k_ray_encode, dim3((unsigned)sdg_cdiv(r * SIXDGS_RAY_IN_PAD, 256)), dim3(256), 0, sdg_stream(stream), ori, dir,
+                     rgb, r, x);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_linear(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n, int relu,
+                  float* y, int64_t ldy, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(m >= 0 && n > 0 && k > 0 && (k % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0 && ldx >= k && ldw >= k && ldy >= n);
+  if (m == 0) return 0;
+  SDG_CHECK_ARG(x && w && y);
+  SDG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0);
+  GemmOperands g = {x, nullptr, w, ldx, 0, ldw, m, n, k, k};
+  return launch_linear<2>(g, b, relu != 0, y, ldy, sdg_stream(stream));
+}
+
+size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
+  if (max_chunk <= 0) max_chunk = 262144;
+  int64_t c = r < max_chunk ? r : max_chunk;
+  if (c < 1) c = 1;
+  return sdg_align((size_t)c * kChunkFloatsPerRay * sizeof(float));
+}
+
+int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
+                    float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(r >= 0 && w);
+  if (r == 0) return 0;
+  SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key));
+  const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float)));
+  if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;
+  const int64_t chunk = chunk_cap < r ? (chunk_cap >= 128 ? chunk_cap / 128 * 128 : chunk_cap) : r;
+  hipStream_t s = sdg_stream(stream);
+  float* x = (float*)ws;
+  float* h1 = x + chunk * SIXDGS_RAY_IN_PAD;
+  float* h2 = h1 + chunk * SIXDGS_HID;
+  for (int64_t r0 = 0; r0 < r; r0 += chunk) {
+    const int64_t m = (r - r0) < chunk ? (r - r0) : chunk;
+    int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
+    if (st) return st;
+    GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
+    if ((st = launch_linear<2>(g1, w->b1, true, h1, SIXDGS_HID, s))) return st;
+    GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID};
+    if ((st = launch_linear<2>(g2, w->b2, true, h2, SIXDGS_HID, s))) return st;
+    // layer 3 consumes the concatenation [h2, x] without materialising it (two A segments)
+    GemmOperands g3 = {h2, x, w->w3, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_HID + SIXDGS_RAY_IN_PAD, m, SIXDGS_HID,
+                       SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID};
+    if ((st = launch_linear<2>(g3, w->b3, true, h1, SIXDGS_HID, s))) return st;
+    float* f = feat ? feat + r0 * SIXDGS_D : h2;
+    GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID};
+    if ((st = launch_linear<2>(g4, w->b4, false, f, SIXDGS_D, s))) return st;
+    if (key) {
+      GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
+      if ((st = launch_linear<2>(g5, w->bk, false, key + r0 * SIXDGS_D, SIXDGS_D, s))) return st;
+    }
+  }
+  return 0;
+}
+
+int sixdgs_q_proj(const float* tokens, const int32_t* d_n_tok, int batch, const sixdgs_scorer_weights* w, float* q,
+                  sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && w);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(tokens && d_n_tok && q);
+  hipLaunchKernelGGL(k_q_proj, dim3(SIXDGS_MAX_TOKENS / kQTok, (unsigned)batch), dim3(SIXDGS_D), 0, sdg_stream(stream), tokens,
+                     d_n_tok, w->wq, w->bq, q);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+}  // extern "C"

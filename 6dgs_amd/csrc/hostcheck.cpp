@@ -1,0 +1,118 @@
+// hostcheck.cpp -- HOST instantiation of device_math.h (the per-thread math of the HIP kernels) behind
+// a tiny C ABI, so the CPU test-suite can compare the product's arithmetic with the oracle and the
+// golden vectors without a GPU.  Contains no kernels; never used by the product path.
+#include <stdlib.h>
+
+#include "device_math.h"
+using namespace sdg;
+
+extern "C" {
+
+void hc_mask_degraded(const float* scale, long long n, int P, unsigned char* mask) {
+  for (long long i = 0; i < n; ++i) {
+    float side;
+    mask[i] = total_rings(scale[3 * i], scale[3 * i + 1], scale[3 * i + 2], (float)P, &side) < (long long)P;
+  }
+}
+
+long long hc_quadricell_centers(const float* scale, long long E, int P, int res, float* points, long long* eid) {
+  long long C = 0;
+  float* table = (float*)malloc(sizeof(float) * res);
+  for (long long e = 0; e < E; ++e) {
+    float a = scale[3 * e], b = scale[3 * e + 1], c = scale[3 * e + 2], side;
+    long long rings = total_rings(a, b, c, (float)P, &side);
+    for (long long ring = 0; ring < rings; ++ring) {
+      Ring rg = ring_params(a, b, c, side, (float)rings, (float)ring);
+      int npts = ring_cells(rg);
+      if (!npts) continue;
+      if (points) {
+        double acc = 0.0;
+        table[0] = 0.f;
+        for (int j = 0; j < res - 1; ++j) { acc += (double)ring_table_increment(rg, j); table[j + 1] = (float)acc; }
+        float last = table[res - 1];
+        for (int j = 0; j < res; ++j) table[j] = kTwoPi * (table[j] / last);
+        for (int j = 0; j < npts; ++j) {
+          int pick = ring_table_pick(table, res, (float)j * rg.dtheta);
+          V3 p = ring_point(rg, table[pick]);
+          points[3 * (C + j)] = p.x; points[3 * (C + j) + 1] = p.y; points[3 * (C + j) + 2] = p.z;
+          eid[C + j] = e;
+        }
+      }
+      C += npts;
+    }
+  }
+  free(table);
+  return C;
+}
+
+long long hc_emit_rays(const float* points, const long long* eid, long long C, const float* normals, const float* centers,
+                       const float* rot4, float* ori, float* dir, long long* mid) {
+  long long r = 0;
+  for (long long i = 0; i < C; ++i) {
+    long long e = eid[i];
+    float R[9];
+    quat_to_rotmat(rot4 + 4 * e, R);
+    V3 pw = rotate(R, v3(points[3 * i], points[3 * i + 1], points[3 * i + 2]));
+    if (!hemisphere_keep(normals[3 * e], pw)) continue;
+    V3 d = normalize_eps(pw);
+    ori[3 * r] = pw.x + centers[3 * e]; ori[3 * r + 1] = pw.y + centers[3 * e + 1]; ori[3 * r + 2] = pw.z + centers[3 * e + 2];
+    dir[3 * r] = d.x; dir[3 * r + 1] = d.y; dir[3 * r + 2] = d.z;
+    mid[r++] = e;
+  }
+  return r;
+}
+
+void hc_sym_eig(const float* mats, long long n, float* vals, float* vecs) {
+  for (long long i = 0; i < n; ++i) sym_eig_3x3(mats + 9 * i, vals + 3 * i, vecs ? vecs + 9 * i : nullptr);
+}
+
+void hc_normals_from_knn(const float* cloud, const long long* knn, long long nq, int k, float* normals) {
+  float* nb = (float*)malloc(sizeof(float) * 3 * k);
+  for (long long q = 0; q < nq; ++q) {
+    for (int j = 0; j < k; ++j)
+      for (int c = 0; c < 3; ++c) nb[3 * j + c] = cloud[3 * knn[q * k + j] + c];
+    V3 n = normal_from_neighbours(nb, k);
+    normals[3 * q] = n.x; normals[3 * q + 1] = n.y; normals[3 * q + 2] = n.z;
+  }
+  free(nb);
+}
+
+long long hc_isocell_dirs(int target, int n0, float* dirs) {
+  int n = isocell_rings(target, n0);
+  long long o = 0;
+  for (int ring = 1; ring <= n; ++ring)
+    for (int j = 0; j < n0 * (2 * ring - 1); ++j, ++o)
+      if (dirs) { V3 d = isocell_dir(n, n0, ring, j); dirs[3 * o] = d.x; dirs[3 * o + 1] = d.y; dirs[3 * o + 2] = d.z; }
+  return o;
+}
+
+void hc_rotate_isocell(const float* dirs, long long K, const float* normals, long long E, float* out) {
+  for (long long e = 0; e < E; ++e) {
+    float Rm[9];
+    isocell_rotation(v3(normals[3 * e], normals[3 * e + 1], normals[3 * e + 2]), Rm);
+    for (long long k = 0; k < K; ++k) {
+      V3 d = isocell_apply(Rm, v3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]));
+      float* o = out + 3 * (e * K + k);
+      o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    }
+  }
+}
+
+void hc_sh_color(const float* sh, int ncoef, const float* dirs, long long R, int deg, float* rgb) {
+  for (long long i = 0; i < R; ++i)
+    for (int ch = 0; ch < 3; ++ch)
+      rgb[3 * i + ch] = sh_channel(sh + (3 * i + ch) * ncoef, 1, deg, -dirs[3 * i], -dirs[3 * i + 1], -dirs[3 * i + 2]);
+}
+
+void hc_ray_input(const float* ori, const float* dir, const float* rgb, long long R, float* x) {
+  for (long long i = 0; i < R; ++i)
+    for (int c = 0; c < 144; ++c) x[144 * i + c] = ray_input_element(ori + 3 * i, dir + 3 * i, rgb + 3 * i, c);
+}
+
+void hc_make_rotation_mat(const float* d, const float* up, float* Rm) { make_rotation_mat(v3(d[0], d[1], d[2]), v3(up[0], up[1], up[2]), Rm); }
+
+int hc_solve_centre(const float* Rm, const float* q, float* c) { return solve_centre(Rm, q, c) ? 1 : 0; }
+
+void hc_pose_errors(const float* gt, const float* pr, float* out2) { pose_errors(gt, pr, out2, out2 + 1); }
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// pose.hip -- per-image pose assembly from the top-k rays (one 64-lane wavefront per image):
+// duplicate-origin filter, least-squares line intersection, exclude_negatives reweighting, viewing
+// direction, rotation assembly, NaN / singular fall-backs, pose errors.
+// replaces pose_estimation/test.py:157-198,216-218,268-288 with line_intersection.py:5-34,75-154 and
+// error_computation.py:3-8.  Batched over images so the loop's per-image device syncs disappear.
+#include "common.h"
+#include "device_math.h"
+
+using namespace sdg;
+
+namespace {
+
+constexpr int kMaxK = 256;
+
+struct PoseArgs {
+  const float* rays_ori;
+  const float* rays_dir;
+  const int64_t* idx;   // [B,k]
+  const float* val;     // [B,k]
+  const float* up;      // [B,3]
+  const float* gt;      // [B,4,4] or null
+  float* c2w;           // [B,4,4]
+  int* status;          // [B]
+  float* w_final;       // [B,k] or null
+  int* n_kept;          // [B] or null
+  float* centre;        // [B,3] or null
+  float* errors;        // [B,2] or null
+  int64_t r;
+  int k;
+};
+
+__global__ void __launch_bounds__(64) k_solve_pose(PoseArgs A) {
+  __shared__ float so[kMaxK * 3];
+  __shared__ float sd[kMaxK * 3];
+  __shared__ float sw[kMaxK];
+  __shared__ float test[kMaxK * 3];
+  __shared__ int cnt[kMaxK];
+  __shared__ int keep[kMaxK];
+  __shared__ int s_nt;
+  const int b = blockIdx.x, lane = threadIdx.x, k = A.k;
+  const int64_t* idx = A.idx + (int64_t)b * k;
+
+  // ---- gather the selected rays (negative / out-of-range indices = padding of a short top-k) -------
+  int k_valid = 0;
+  for (int i = lane; i < k; i += 64) {
+    const int64_t id = idx[i];
+    const bool ok = id >= 0 && id < A.r;
+    for (int c = 0; c < 3; ++c) {
+      so[3 * i + c] = ok ? A.rays_ori[3 * id + c] : NAN;
+      sd[3 * i + c] = ok ? A.rays_dir[3 * id + c] : NAN;
+    }
+    sw[i] = ok ? A.val[(int64_t)b * k + i] : 0.f;
+  }
+  __syncthreads();
+  // padding entries sit at the tail (sorted top-k): count the valid prefix
+  for (int i = 0; i < k; ++i) k_valid += (idx[i] >= 0 && idx[i] < A.r) ? 1 : 0;
+  const int kv = k_valid;
+
+  // ---- a17: torch.unique(rows, counts) + isin(assume_unique=True).any(dim=1)  (test.py:157-162) ------
+  for (int i = lane; i < kv; i += 64) {
+    int c = 0;
+    for (int j = 0; j < kv; ++j)
+      c += (so[3 * i] == so[3 * j] && so[3 * i + 1] == so[3 * j + 1] && so[3 * i + 2] == so[3 * j + 2]) ? 1 : 0;
+    cnt[i] = c;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int nt = 0;
+    for (int i = 0; i < kv; ++i)
+      if (cnt[i] == 1) {
+        test[nt++] = so[3 * i];
+        test[nt++] = so[3 * i + 1];
+        test[nt++] = so[3 * i + 2];
+      }
+    s_nt = nt;
+  }
+  __syncthreads();
+  const int nt = s_nt, ne = 3 * kv;
+  // torch picks the sort-based algorithm unless the test set is small:
+  // test.numel() < (int64)(10.0f * pow(elements.numel(), 0.145))
+  const long long small_thr = (long long)(10.0 * pow((double)ne, 0.145));
+  const bool sorting = !((long long)nt < small_thr);
+  for (int i = lane; i < kv; i += 64) {
+    int any = 0;
+    for (int c = 0; c < 3 && !any; ++c) {
+      const int p = 3 * i + c;
+      const float v = so[p];
+      for (int t = 0; t < nt && !any; ++t) any = (test[t] == v) ? 1 : 0;
+      if (sorting)
+        for (int q2 = p + 1; q2 < ne && !any; ++q2) any = (so[q2] == v) ? 1 : 0;
+    }
+    keep[i] = any;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+
+  // ---- the rest is a short sequential tail (k <= 256), evaluated in index order like the oracle ------
+  int m = 0;
+  for (int i = 0; i < kv; ++i)
+    if (keep[i]) {
+      for (int c = 0; c < 3; ++c) { so[3 * m + c] = so[3 * i + c]; sd[3 * m + c] = sd[3 * i + c]; }
+      sw[m] = sw[i];
+      ++m;
+    }
+  float sum = 0.f;
+  for (int i = 0; i < m; ++i) sum += sw[i];
+  for (int i = 0; i < m; ++i) sw[i] = sw[i] / sum;
+  // a18: R = sum (I - d d^T), q = sum (I - d d^T) o   (unweighted, test.py:169-171)
+  float Rm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qv[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < m; ++i) {
+    const float d0 = sd[3 * i], d1 = sd[3 * i + 1], d2 = sd[3 * i + 2];
+    const float o0 = so[3 * i], o1 = so[3 * i + 1], o2 = so[3 * i + 2];
+    const float P[9] = {1.f - d0 * d0, 0.f - d0 * d1, 0.f - d0 * d2, 0.f - d1 * d0, 1.f - d1 * d1,
+                        0.f - d1 * d2, 0.f - d2 * d0, 0.f - d2 * d1, 1.f - d2 * d2};
+    for (int a = 0; a < 9; ++a) Rm[a] += P[a];
+    qv[0] += (P[0] * o0 + P[1] * o1) + P[2] * o2;
+    qv[1] += (P[3] * o0 + P[4] * o1) + P[5] * o2;
+    qv[2] += (P[6] * o0 + P[7] * o1) + P[8] * o2;
+  }
+  float ctr[3];
+  const bool ok = solve_centre(Rm, qv, ctr);
+  // exclude_negatives (line_intersection.py:29-34) and renormalise; the second solve of the reference
+  // (test.py:177-179) is unweighted too and therefore returns the same centre
+  for (int i = 0; i < m; ++i) {
+    const float v0 = ctr[0] - so[3 * i], v1 = ctr[1] - so[3 * i + 1], v2 = ctr[2] - so[3 * i + 2];
+    const float dd = (v0 * sd[3 * i] + v1 * sd[3 * i + 1]) + v2 * sd[3 * i + 2];
+    sw[i] = sw[i] * (dd > 0.f ? 1.f : 0.f);
+  }
+  sum = 0.f;
+  for (int i = 0; i < m; ++i) sum += sw[i];
+  for (int i = 0; i < m; ++i) sw[i] = sw[i] / sum;
+  float wd[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < m; ++i) {
+    wd[0] += sd[3 * i] * sw[i];
+    wd[1] += sd[3 * i + 1] * sw[i];
+    wd[2] += sd[3 * i + 2] * sw[i];
+  }
+  const float wn = sqrtf((wd[0] * wd[0] + wd[1] * wd[1]) + wd[2] * wd[2]);
+  const V3 neg = v3(-(wd[0] / wn), -(wd[1] / wn), -(wd[2] / wn));
+  const V3 upv = v3(A.up[3 * b], A.up[3 * b + 1], A.up[3 * b + 2]);
+  float Rw[9];
+  make_rotation_mat(neg, upv, Rw);
+  int st = ok ? 0 : 4;
+  if (det3(Rw) < 1.0e-7f) {  // test.py:194-196
+    st |= 1;
+    for (int i = 0; i < 9; ++i) Rw[i] = (i % 4 == 0) ? 1.f : 0.f;
+  }
+  float Ri[9];
+  if (!inv3(Rw, Ri))
+    for (int i = 0; i < 9; ++i) Ri[i] = NAN;
+  float out[16];
+  for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) out[4 * r + c] = Ri[3 * r + c];
+    out[4 * r + 3] = ctr[r];
+  }
+  bool nan = false;
+  for (int i = 0; i < 16; ++i) nan = nan || !(out[i] == out[i]);
+  if (nan) {  // test.py:216-218
+    st |= 2;
+    for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.f : 0.f;
+  }
+  for (int i = 0; i < 16; ++i) A.c2w[16 * b + i] = out[i];
+  A.status[b] = st;
+  if (A.centre)
+    for (int c = 0; c < 3; ++c) A.centre[3 * b + c] = ctr[c];
+  if (A.n_kept) A.n_kept[b] = m;
+  if (A.w_final) {
+    int j = 0;
+    for (int i = 0; i < k; ++i) A.w_final[(int64_t)b * k + i] = (i < kv && keep[i]) ? sw[j++] : 0.f;
+  }
+  if (A.errors) {
+    float te = NAN, ae = NAN;
+    if (A.gt) pose_errors(A.gt + 16 * b, out, &te, &ae);
+    A.errors[2 * b] = te;
+    A.errors[2 * b + 1] = ae;
+  }
+}
+
+}  // namespace
+
+extern "C" int sixdgs_solve_pose(const float* rays_ori, const float* rays_dir, int64_t r, const int64_t* idx, const float* val,
+                                 int k, const float* up, const float* gt_c2w, int batch, float* c2w, int32_t* status,
+                                 float* w_final, int32_t* n_kept, float* centre, float* errors, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && k >= 1 && k <= kMaxK && r >= 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(rays_ori && rays_dir && idx && val && up && c2w && status);
+  PoseArgs A = {rays_ori, rays_dir, idx, val, up, gt_c2w, c2w, status, w_final, n_kept, centre, errors, r, k};
+  hipLaunchKernelGGL(k_solve_pose, dim3((unsigned)batch), dim3(64), 0, sdg_stream(stream), A);
+  SDG_LAUNCH_OK();
+  return 0;
+}

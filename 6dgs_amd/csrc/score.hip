@@ -1,0 +1,444 @@
+// score.hip -- the per-image part of the scorer:
+//   logits[t][r] = q[t] . key[r] / sqrt(384)           (fp32 MFMA tile kernel, stores + row stats)
+//   score[r]     = sum_t exp(logits[t][r] - max_t) / sumexp_t      (HBM-streaming reduce)
+//   top-k        = radix select over the score bits + ordered gather + small sort
+// replaces MultiHeadAttention.forward (our_multihead_attention.py:70-79,4-12), the column sum of
+// IdentificationModule.run_attention (identification_module.py:80-82) and torch.topk (:131).
+//
+// The softmax runs over the RAY axis (rows = image tokens): its row statistics must be complete
+// before any column sum can be formed, so the [T, R] logits are written once to a caller-provided
+// workspace (1 KB per ray and image, token-major) instead of recomputing the contraction in a second
+// pass: at R = 32 M that is 64 GB of extra HBM traffic (~12 ms) against ~40 ms of fp32 MFMA work.
+#include "gemm_kernel.h"
+
+using namespace sdg;
+
+namespace {
+
+constexpr int kT = SIXDGS_MAX_TOKENS;
+constexpr float kSqrtD = 19.595917942265423f;  // math.sqrt(384) rounded to fp32, as torch does for `/ python_float`
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: logits tile + online row statistics.  One workgroup = 128 tokens x a contiguous group of
+// 128-ray tiles of one image.
+// ------------------------------------------------------------------------------------------------
+struct LogitsArgs {
+  const float* q;        // [B,256,384]
+  const int* n_tok;      // [B]
+  const float* key;      // [R,384]
+  float* logits;         // [Bg,256,ldl]
+  float* partial;        // [Bg,G,256,2]
+  int64_t r, ldl;
+  int tiles_per_group, n_tiles, n_groups;
+  int b0;                // first image of this group in q / n_tok
+};
+
+__global__ void __launch_bounds__(256, 2) k_logits(LogitsArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * GemmSmem<2>::kStageFloats];
+  __shared__ float part[2][128][2];
+  const int bl = blockIdx.y;            // image within the group
+  const int b = A.b0 + bl;
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = (int)(w >> 1), m_tile = (int)(w & 1u);
+  const int M = A.n_tok[b];
+  const int row0 = m_tile * 128;
+  float* pout = A.partial + (((int64_t)bl * A.n_groups + grp) * kT + row0) * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float m_run = -INFINITY, s_run = 0.f;   // owned by thread tid < 128 for token row0 + tid
+  if (row0 < M) {
+    GemmOperands g = {A.q + (int64_t)b * kT * SIXDGS_D, nullptr, A.key, SIXDGS_D, 0, SIXDGS_D, M, A.r, SIXDGS_D, SIXDGS_D};
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl;
+    const int t_begin = grp * A.tiles_per_group;
+    const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int64_t col0 = (int64_t)tile * kBN;
+      f32x16 acc[2][2];
+      gemm_mainloop<2>(g, row0, col0, smem, acc);
+      const int64_t c0 = col0 + acc_col(wn, 0, lane), c1 = col0 + acc_col(wn, 1, lane);
+      const bool v0 = c0 < A.r, v1 = c1 < A.r;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + acc_row(wm, tm, r, lane);
+          const float l0 = acc[tm][0][r] / kSqrtD, l1 = acc[tm][1][r] / kSqrtD;
+          if (row < M) {
+            if (v0) lg[(int64_t)row * A.ldl + c0] = l0;
+            if (v1) lg[(int64_t)row * A.ldl + c1] = l1;
+          }
+          float mx = fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+          float sm = 0.f;
+          if (mx > -INFINITY) sm = (v0 ? expf(l0 - mx) : 0.f) + (v1 ? expf(l1 - mx) : 0.f);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+          if ((lane & 31) == 0) {
+            const int lr = acc_row(wm, tm, r, lane);
+            part[wn][lr][0] = mx;
+            part[wn][lr][1] = sm;
+          }
+        }
+      __syncthreads();
+      if (tid < 128) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float mt = part[h][tid][0], st = part[h][tid][1];
+          if (mt > -INFINITY) {
+            const float mn = fmaxf(m_run, mt);
+            s_run = s_run * expf(m_run - mn) + st * expf(mt - mn);
+            m_run = mn;
+          }
+        }
+      }
+      // the next tile's mainloop starts with a barrier before `part` can be overwritten again
+    }
+  }
+  if (tid < 128) {
+    pout[2 * tid] = m_run;
+    pout[2 * tid + 1] = s_run;
+  }
+}
+
+// merge the per-group partial statistics: stats[b][t] = (max, sumexp)
+__global__ void __launch_bounds__(kT) k_merge_stats(const float* __restrict__ partial, int n_groups, float* __restrict__ stats) {
+  const int bl = blockIdx.x, t = threadIdx.x;
+  const float* p = partial + (int64_t)bl * n_groups * kT * 2;
+  float m = -INFINITY, s = 0.f;
+  for (int g = 0; g < n_groups; ++g) {
+    const float mt = p[((int64_t)g * kT + t) * 2], st = p[((int64_t)g * kT + t) * 2 + 1];
+    if (mt > -INFINITY) {
+      const float mn = fmaxf(m, mt);
+      s = s * expf(m - mn) + st * expf(mt - mn);
+      m = mn;
+    }
+  }
+  stats[((int64_t)bl * kT + t) * 2] = m;
+  stats[((int64_t)bl * kT + t) * 2 + 1] = s;
+}
+
+// pass 2: score[r] = sum_{t < T} exp(l[t][r] - max_t) / sumexp_t   (softmax over rays, summed over tokens)
+__global__ void __launch_bounds__(256) k_score_reduce(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ stats,
+                                                       const int* __restrict__ n_tok, int b0, int64_t R, float* __restrict__ scores,
+                                                       int64_t score_stride) {
+  __shared__ float st[kT][2];
+  const int bl = blockIdx.y;
+  const int T = n_tok[b0 + bl];
+  for (int i = threadIdx.x; i < kT * 2; i += blockDim.x) (&st[0][0])[i] = stats[(int64_t)bl * kT * 2 + i];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R) return;
+  const float* l = logits + (int64_t)bl * kT * ldl + j;
+  float s = 0.f;
+#pragma unroll 8
+  for (int t = 0; t < T; ++t) s += expf(l[(int64_t)t * ldl] - st[t][0]) / st[t][1];
+  scores[(int64_t)bl * score_stride + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k: 4-pass MSB radix select on an order-preserving key, ordered gather, bitonic sort
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned score_key(float v) {
+  unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct SelectState {
+  unsigned prefix;   // high bits of the k-th largest key decided so far
+  unsigned remain;   // how many are still needed among keys matching the prefix
+};
+// Re-derive the selection after `passes` histogram passes (each block does this redundantly: <= 3x256 bins).
+__device__ SelectState select_state(const unsigned* hist /*[4][256] of this image*/, int passes, unsigned k, unsigned* sm /*[256]*/) {
+  SelectState st = {0u, k};
+  for (int p = 0; p < passes; ++p) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sm[i] = hist[p * 256 + i];
+    __syncthreads();
+    // every thread scans from the top bin (256 adds; uniform)
+    unsigned acc = 0, digit = 0, rem = st.remain;
+    for (int d = 255; d >= 0; --d) {
+      const unsigned c = sm[d];
+      if (acc + c >= st.remain) { digit = (unsigned)d; rem = st.remain - acc; break; }
+      acc += c;
+    }
+    st.prefix |= digit << (24 - 8 * p);
+    st.remain = rem;
+  }
+  return st;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ scores, int64_t stride, int64_t R, unsigned k,
+                                                    unsigned* __restrict__ hist_all) {
+  __shared__ unsigned sm[256];
+  __shared__ unsigned lh[256];
+  const int b = blockIdx.y;
+  unsigned* hist = hist_all + (int64_t)b * 4 * 256;
+  const SelectState st = select_state(hist, PASS, k, sm);
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const float* s = scores + (int64_t)b * stride;
+  constexpr unsigned hi_mask = PASS == 0 ? 0u : (0xffffffffu << (32 - 8 * PASS));
+  constexpr int shift = 24 - 8 * PASS;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned key = score_key(s[i]);
+    if ((key & hi_mask) == st.prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x)
+    if (lh[i]) atomicAdd(&hist[PASS * 256 + i], lh[i]);
+}
+
+// ordered gather.  Block c owns the contiguous index range [c*span, (c+1)*span).
+// COUNT: counts[b][c] = (#greater, #equal) in the range.  WRITE: emits candidates in index order:
+// greater ones at their global rank, equal ones after all greater ones while rank_eq < remain.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_topk_gather(const float* __restrict__ scores, int64_t stride, int64_t R, unsigned k,
+                                                      const unsigned* __restrict__ hist_all, int64_t span,
+                                                      unsigned* __restrict__ counts /*[B][NB][2]*/,
+                                                      const unsigned* __restrict__ offs /*[B][NB][2] exclusive*/,
+                                                      unsigned* __restrict__ cand_key, int64_t* __restrict__ cand_idx, int topk) {
+  __shared__ unsigned sm[256];
+  __shared__ int sc[2][5];
+  const int b = blockIdx.y;
+  const SelectState st = select_state(hist_all + (int64_t)b * 4 * 256, 4, k, sm);
+  const unsigned thr = st.prefix;
+  const float* s = scores + (int64_t)b * stride;
+  const int64_t i0 = (int64_t)blockIdx.x * span, i1 = min(i0 + span, R);
+  unsigned run_g = 0, run_e = 0;
+  unsigned base_g = 0, base_e = 0, n_greater = 0;
+  if (WRITE) {
+    base_g = offs[((int64_t)b * gridDim.x + blockIdx.x) * 2];
+    base_e = offs[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 1];
+    n_greater = k - st.remain;
+  }
+  for (int64_t c0 = i0; c0 < i1; c0 += 256) {
+    const int64_t i = c0 + threadIdx.x;
+    unsigned key = 0;
+    bool gt = false, eq = false;
+    if (i < i1) {
+      key = score_key(s[i]);
+      gt = key > thr;
+      eq = key == thr;
+    }
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    const int lane = sdg_lane(), wv = sdg_wave();
+    if (lane == 0) { sc[0][wv] = __popcll(bg); sc[1][wv] = __popcll(be); }
+    __syncthreads();
+    unsigned og = 0, oe = 0, tg = 0, te = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (w2 < wv) { og += sc[0][w2]; oe += sc[1][w2]; }
+      tg += sc[0][w2];
+      te += sc[1][w2];
+    }
+    __syncthreads();
+    if (WRITE) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (gt) {
+        const unsigned pos = base_g + run_g + og + __popcll(bg & below);
+        if (pos < (unsigned)topk) { cand_key[(int64_t)b * topk + pos] = key; cand_idx[(int64_t)b * topk + pos] = i; }
+      } else if (eq) {
+        const unsigned re = base_e + run_e + oe + __popcll(be & below);
+        if (re < st.remain) {
+          const unsigned pos = n_greater + re;
+          if (pos < (unsigned)topk) { cand_key[(int64_t)b * topk + pos] = key; cand_idx[(int64_t)b * topk + pos] = i; }
+        }
+      }
+    }
+    run_g += tg;
+    run_e += te;
+  }
+  if (!WRITE && threadIdx.x == 0) {
+    counts[((int64_t)b * gridDim.x + blockIdx.x) * 2] = run_g;
+    counts[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 1] = run_e;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_topk_scan(const unsigned* __restrict__ counts, int nb, unsigned* __restrict__ offs) {
+  __shared__ unsigned sm[17];
+  const int b = blockIdx.x;
+  for (int comp = 0; comp < 2; ++comp) {
+    unsigned base = 0;
+    for (int c0 = 0; c0 < nb; c0 += 1024) {
+      const int i = c0 + threadIdx.x;
+      const unsigned v = i < nb ? counts[((int64_t)b * nb + i) * 2 + comp] : 0u;
+      unsigned tot;
+      const unsigned ex = sdg_block_exclusive_scan<unsigned, 16>(v, sm, &tot);
+      if (i < nb) offs[((int64_t)b * nb + i) * 2 + comp] = base + ex;
+      base += tot;
+    }
+  }
+}
+
+// sort the <= 1024 candidates by (key desc, index asc) and emit idx/val; pads with (-1, NaN)
+__global__ void __launch_bounds__(1024) k_topk_sort(const unsigned* __restrict__ cand_key, const int64_t* __restrict__ cand_idx,
+                                                     int topk, int k_eff, int64_t* __restrict__ idx, float* __restrict__ val) {
+  __shared__ unsigned sk[1024];
+  __shared__ long long si[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < k_eff) { sk[t] = cand_key[(int64_t)b * topk + t]; si[t] = cand_idx[(int64_t)b * topk + t]; }
+  else { sk[t] = 0u; si[t] = 0x7fffffffffffffffll; }
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      const int p = t ^ strd;
+      if (p > t) {
+        const bool up = (t & size) == 0;   // "up" block: best-first order
+        const unsigned ka = sk[t], kb = sk[p];
+        const long long ia = si[t], ib = si[p];
+        const bool a_first = ka > kb || (ka == kb && ia < ib);   // a ranks before b
+        if (up ? !a_first : a_first) { sk[t] = kb; sk[p] = ka; si[t] = ib; si[p] = ia; }
+      }
+      __syncthreads();
+    }
+  if (t < topk) {
+    if (t < k_eff) { idx[(int64_t)b * topk + t] = si[t]; val[(int64_t)b * topk + t] = key_score(sk[t]); }
+    else { idx[(int64_t)b * topk + t] = -1; val[(int64_t)b * topk + t] = NAN; }
+  }
+}
+
+struct TopkPlan {
+  int nb;          // gather blocks per image
+  int64_t span;    // indices per gather block
+  size_t off_hist, off_counts, off_offs, off_ckey, off_cidx, bytes;
+};
+TopkPlan topk_plan(int64_t r, int batch, int topk) {
+  TopkPlan p;
+  int64_t nb = sdg_cdiv(r, 256 * 16);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  p.nb = (int)nb;
+  p.span = sdg_cdiv(sdg_cdiv(r, nb), 256) * 256;
+  if (p.span < 256) p.span = 256;
+  size_t o = 0;
+  p.off_hist = o;   o += sdg_align((size_t)batch * 4 * 256 * sizeof(unsigned));
+  p.off_counts = o; o += sdg_align((size_t)batch * nb * 2 * sizeof(unsigned));
+  p.off_offs = o;   o += sdg_align((size_t)batch * nb * 2 * sizeof(unsigned));
+  p.off_ckey = o;   o += sdg_align((size_t)batch * topk * sizeof(unsigned));
+  p.off_cidx = o;   o += sdg_align((size_t)batch * topk * sizeof(int64_t));
+  p.bytes = o;
+  return p;
+}
+
+int run_topk(const float* scores, int64_t stride, int64_t r, int batch, int topk, int64_t* idx, float* val, char* ws,
+             hipStream_t s) {
+  const TopkPlan p = topk_plan(r, batch, topk);
+  unsigned* hist = (unsigned*)(ws + p.off_hist);
+  unsigned* counts = (unsigned*)(ws + p.off_counts);
+  unsigned* offs = (unsigned*)(ws + p.off_offs);
+  unsigned* ckey = (unsigned*)(ws + p.off_ckey);
+  int64_t* cidx = (int64_t*)(ws + p.off_cidx);
+  const int k_eff = (int)(r < topk ? r : topk);
+  if (k_eff > 0) {
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)batch * 4 * 256 * sizeof(unsigned), s);
+    if (e != hipSuccess) return (int)e;
+    int64_t hb = sdg_cdiv(r, 256 * 8);
+    if (hb > 1024) hb = 1024;
+    const dim3 hg((unsigned)hb, (unsigned)batch);
+    hipLaunchKernelGGL(k_topk_hist<0>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
+    hipLaunchKernelGGL(k_topk_hist<1>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
+    hipLaunchKernelGGL(k_topk_hist<2>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
+    hipLaunchKernelGGL(k_topk_hist<3>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
+    const dim3 gg((unsigned)p.nb, (unsigned)batch);
+    hipLaunchKernelGGL(k_topk_gather<false>, gg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, p.span, counts, offs,
+                       ckey, cidx, topk);
+    hipLaunchKernelGGL(k_topk_scan, dim3((unsigned)batch), dim3(1024), 0, s, counts, p.nb, offs);
+    hipLaunchKernelGGL(k_topk_gather<true>, gg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, p.span, counts, offs,
+                       ckey, cidx, topk);
+  }
+  hipLaunchKernelGGL(k_topk_sort, dim3((unsigned)batch), dim3(1024), 0, s, ckey, cidx, topk, k_eff, idx, val);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+struct ScorePlan {
+  int64_t ldl;
+  int n_tiles, tiles_per_group, n_groups;
+  size_t per_image_logits, per_image_partial, per_image_stats, per_image_scores, topk_bytes;
+};
+ScorePlan score_plan(int64_t r, int batch, int topk) {
+  ScorePlan p;
+  p.ldl = sdg_cdiv(r > 0 ? r : 1, 128) * 128;
+  p.n_tiles = (int)sdg_cdiv(r > 0 ? r : 1, kBN);
+  p.tiles_per_group = (int)sdg_cdiv(p.n_tiles, 2048);
+  p.n_groups = (int)sdg_cdiv(p.n_tiles, p.tiles_per_group);
+  p.per_image_logits = sdg_align((size_t)kT * p.ldl * sizeof(float));
+  p.per_image_partial = sdg_align((size_t)p.n_groups * kT * 2 * sizeof(float));
+  p.per_image_stats = sdg_align((size_t)kT * 2 * sizeof(float));
+  p.per_image_scores = sdg_align((size_t)p.ldl * sizeof(float));
+  p.topk_bytes = topk_plan(r, batch, topk).bytes;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk) { return topk_plan(r, batch < 1 ? 1 : batch, topk).bytes; }
+
+int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws, size_t ws_bytes,
+                sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG((scores || r == 0) && idx && val && ws);
+  if (ws_bytes < topk_plan(r, batch, topk).bytes) return SIXDGS_E_WORKSPACE;
+  return run_topk(scores, r, r, batch, topk, idx, val, (char*)ws, sdg_stream(stream));
+}
+
+size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
+  if (batch < 1) batch = 1;
+  const ScorePlan p = score_plan(r, batch, topk);
+  return p.topk_bytes + (size_t)batch * (p.per_image_logits + p.per_image_partial + p.per_image_stats + p.per_image_scores);
+}
+
+int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
+                      int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(q && d_n_tok && (key || r == 0) && idx && val && ws);
+  SDG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  ScorePlan p = score_plan(r, batch, topk);
+  const size_t per_image = p.per_image_logits + p.per_image_partial + p.per_image_stats + p.per_image_scores;
+  // largest image group whose logits + top-k scratch fit the caller's workspace
+  int64_t bg = batch > 65535 ? 65535 : batch;
+  while (bg >= 1 && topk_plan(r, (int)bg, topk).bytes + (size_t)bg * per_image > ws_bytes) --bg;
+  if (bg < 1) return SIXDGS_E_WORKSPACE;
+  p.topk_bytes = topk_plan(r, (int)bg, topk).bytes;
+  char* base = (char*)ws;
+  char* topk_ws = base;
+  float* logits = (float*)(base + p.topk_bytes);
+  float* partial = (float*)((char*)logits + (size_t)bg * p.per_image_logits);
+  float* stats = (float*)((char*)partial + (size_t)bg * p.per_image_partial);
+  float* sc_ws = (float*)((char*)stats + (size_t)bg * p.per_image_stats);
+  const int64_t ldl_img = (int64_t)(p.per_image_logits / sizeof(float)) / kT;  // == p.ldl (alignment keeps it)
+  (void)ldl_img;
+  for (int b0 = 0; b0 < batch; b0 += (int)bg) {
+    const int nb = (int)((batch - b0) < bg ? (batch - b0) : bg);
+    float* sc = scores ? scores + (int64_t)b0 * r : sc_ws;
+    const int64_t sc_stride = scores ? r : (int64_t)(p.per_image_scores / sizeof(float));
+    if (r > 0) {
+      LogitsArgs A = {q, d_n_tok, key, logits, partial, r, (int64_t)(p.per_image_logits / sizeof(float) / kT),
+                      p.tiles_per_group, p.n_tiles, p.n_groups, b0};
+      hipLaunchKernelGGL(k_logits, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
+      hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
+                         d_n_tok, b0, r, sc, sc_stride);
+      SDG_LAUNCH_OK();
+      if (row_stats) {
+        hipError_t e = hipMemcpyAsync(row_stats + (int64_t)b0 * kT * 2, stats, (size_t)nb * kT * 2 * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+      }
+    }
+    int st = run_topk(sc, sc_stride, r, nb, topk, idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, topk_ws, s);
+    if (st) return st;
+  }
+  return 0;
+}
+
+}  // extern "C"

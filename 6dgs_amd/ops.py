@@ -1,0 +1,320 @@
+"""Tensor-level front end of the C ABI (include/sixdgs.h): PyTorch owns memory and streams, the HIP
+library does the work.  Every function requires CUDA(ROCm) tensors -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ScorerWeights, check
+
+D = 384
+RAY_IN_PAD = 144
+TOK_IN = 398
+MAX_TOKENS = 256
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("6dgs_amd: tensors must live on the GPU (no CPU fallback on the product path)")
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _i64(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.int64).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry
+# ---------------------------------------------------------------------------------------------
+def mask_degraded(log_scale: torch.Tensor, target_points: int = 50) -> torch.Tensor:
+    log_scale = _f32(log_scale)
+    _need_gpu(log_scale)
+    n = log_scale.shape[0]
+    out = torch.empty(n, dtype=torch.uint8, device=log_scale.device)
+    check(_lib.load().sixdgs_mask_degraded(_p(log_scale), n, int(target_points), _p(out), _stream()), "mask_degraded")
+    return out.bool()
+
+
+def sym_eig_3x3(mats: torch.Tensor, eigenvectors: bool = True):
+    mats = _f32(mats)
+    _need_gpu(mats)
+    shape = mats.shape[:-2]
+    m = mats.reshape(-1, 3, 3)
+    vals = torch.empty(m.shape[0], 3, device=m.device)
+    vecs = torch.empty(m.shape[0], 3, 3, device=m.device) if eigenvectors else None
+    check(_lib.load().sixdgs_sym_eig_3x3(_p(m), m.shape[0], _p(vals), _p(vecs), _stream()), "sym_eig_3x3")
+    return vals.reshape(*shape, 3), (vecs.reshape(*shape, 3, 3) if eigenvectors else None)
+
+
+def normals_knn(query: torch.Tensor, cloud: torch.Tensor, k: int = 20, return_knn: bool = False):
+    query, cloud = _f32(query), _f32(cloud)
+    _need_gpu(query, cloud)
+    nq = query.shape[0]
+    out = torch.empty(nq, 3, device=query.device)
+    knn = torch.empty(nq, k, dtype=torch.int64, device=query.device) if return_knn else None
+    check(_lib.load().sixdgs_normals_knn(_p(query), nq, _p(cloud), cloud.shape[0], int(k), _p(out), _p(knn), _stream()),
+          "normals_knn")
+    return (out, knn) if return_knn else out
+
+
+def quadricell_centers(scale: torch.Tensor, target_points: int = 50, table_res: int = 1000):
+    """a6 alone: (points[C,3], ellipsoid_id[C]) for activated semi axes scale[E,3]."""
+    scale = _f32(scale)
+    _need_gpu(scale)
+    lib = _lib.load()
+    e = scale.shape[0]
+    dev = scale.device
+    counts = torch.empty(max(e, 1), dtype=torch.int64, device=dev)
+    offs = torch.empty(max(e, 1), dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)
+    check(lib.sixdgs_quadricell_cell_counts(_p(scale), e, int(target_points), _p(counts), _p(offs), _p(total), _stream()),
+          "quadricell_cell_counts")
+    c = int(total[0].item())
+    pts = torch.empty(c, 3, device=dev)
+    eid = torch.empty(c, dtype=torch.int64, device=dev)
+    if c:
+        check(lib.sixdgs_quadricell_centers(_p(scale), e, int(target_points), int(table_res), _p(offs), _p(pts), _p(eid),
+                                            _stream()), "quadricell_centers")
+    return pts, eid
+
+
+def emit_quadricell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel: Optional[torch.Tensor], normals, target_points: int = 50,
+                    table_res: int = 1000, scale_is_log: bool = True, want_rgb: bool = True):
+    """a1+a6+a7+a10: returns ori[R,3], dir[R,3], rgb[R,3] (or None), src[R] (Gaussian id), n_cells."""
+    xyz, scale, rot, normals = _f32(xyz), _f32(scale), _f32(rot), _f32(normals)
+    _need_gpu(xyz, scale, rot, normals)
+    lib = _lib.load()
+    dev = xyz.device
+    sel_t = _i64(sel) if sel is not None else None
+    e = sel_t.shape[0] if sel_t is not None else xyz.shape[0]
+    assert normals.shape[0] == e
+    counts = torch.empty(max(e, 1), dtype=torch.int64, device=dev)
+    offs = torch.empty(max(e, 1), dtype=torch.int64, device=dev)
+    total = torch.zeros(2, dtype=torch.int64, device=dev)
+    check(lib.sixdgs_emit_quadricell_count(_p(xyz), _p(scale), int(scale_is_log), _p(rot), _p(sel_t), e, _p(normals),
+                                           int(target_points), int(table_res), _p(counts), _p(offs), _p(total), _stream()),
+          "emit_quadricell_count")
+    tot = total.tolist()  # the one host sync of the emitter (the reference syncs at sampling.py:145)
+    r, n_cells = int(tot[0]), int(tot[1])
+    ori = torch.empty(r, 3, device=dev)
+    dr = torch.empty(r, 3, device=dev)
+    src = torch.empty(r, dtype=torch.int64, device=dev)
+    rgb = None
+    n_coef = 1
+    if want_rgb:
+        f_dc, f_rest = _f32(f_dc), _f32(f_rest)
+        n_coef = 1 + f_rest.shape[1]
+        rgb = torch.empty(r, 3, device=dev)
+    if r:
+        check(lib.sixdgs_emit_quadricell_write(_p(xyz), _p(scale), int(scale_is_log), _p(rot), _p(f_dc if want_rgb else None),
+                                               _p(f_rest if want_rgb else None), int(sh_degree), int(n_coef), _p(sel_t), e,
+                                               _p(normals), int(target_points), int(table_res), _p(offs), _p(ori), _p(dr),
+                                               _p(rgb), _p(src), _stream()), "emit_quadricell_write")
+    return ori, dr, rgb, src, n_cells
+
+
+def isocell_distribution(ray_target: int, n0: int = 1, device="cuda") -> torch.Tensor:
+    lib = _lib.load()
+    cnt = C.c_int64(0)
+    check(lib.sixdgs_isocell_distribution(int(ray_target), int(n0), None, C.byref(cnt), _stream()), "isocell_distribution")
+    out = torch.empty(cnt.value, 3, device=device)
+    check(lib.sixdgs_isocell_distribution(int(ray_target), int(n0), _p(out), C.byref(cnt), _stream()), "isocell_distribution")
+    return out
+
+
+def rotate_isocell(dirs: torch.Tensor, normals: torch.Tensor) -> torch.Tensor:
+    dirs, normals = _f32(dirs), _f32(normals)
+    _need_gpu(dirs, normals)
+    out = torch.empty(normals.shape[0], dirs.shape[0], 3, device=dirs.device)
+    check(_lib.load().sixdgs_rotate_isocell(_p(dirs), dirs.shape[0], _p(normals), normals.shape[0], _p(out), _stream()),
+          "rotate_isocell")
+    return out
+
+
+def emit_isocell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel, normals, dirs, scale_is_log: bool = True,
+                 want_rgb: bool = True, want_src: bool = True):
+    xyz, scale, rot, normals, dirs = _f32(xyz), _f32(scale), _f32(rot), _f32(normals), _f32(dirs)
+    _need_gpu(xyz, scale, rot, normals, dirs)
+    dev = xyz.device
+    sel_t = _i64(sel) if sel is not None else None
+    e = sel_t.shape[0] if sel_t is not None else xyz.shape[0]
+    k = dirs.shape[0]
+    ori = torch.empty(e * k, 3, device=dev)
+    dr = torch.empty(e * k, 3, device=dev)
+    rgb = torch.empty(e * k, 3, device=dev) if want_rgb else None
+    src = torch.empty(e * k, dtype=torch.int64, device=dev) if want_src else None
+    n_coef = 1
+    if want_rgb:
+        f_dc, f_rest = _f32(f_dc), _f32(f_rest)
+        n_coef = 1 + f_rest.shape[1]
+    check(_lib.load().sixdgs_emit_isocell(_p(xyz), _p(scale), int(scale_is_log), _p(rot), _p(f_dc if want_rgb else None),
+                                          _p(f_rest if want_rgb else None), int(sh_degree), int(n_coef), _p(sel_t), e,
+                                          _p(normals), _p(dirs), k, _p(ori), _p(dr), _p(rgb), _p(src), _stream()), "emit_isocell")
+    return ori, dr, rgb, src
+
+
+def eval_sh_color(sh: torch.Tensor, dirs: torch.Tensor, sh_degree: int) -> torch.Tensor:
+    sh, dirs = _f32(sh), _f32(dirs)
+    _need_gpu(sh, dirs)
+    out = torch.empty(dirs.shape[0], 3, device=dirs.device)
+    check(_lib.load().sixdgs_eval_sh_color(_p(sh), sh.shape[-1], _p(dirs), dirs.shape[0], int(sh_degree), _p(out), _stream()),
+          "eval_sh_color")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# scorer
+# ---------------------------------------------------------------------------------------------
+class PackedWeights:
+    """Device copy of the scorer weights in the kernels' padded layout + the C struct of pointers."""
+
+    KEYS = ("ray_preprocessor.mlp.0", "ray_preprocessor.mlp.2", "ray_preprocessor.mlp2.0", "ray_preprocessor.mlp2.2",
+            "attention.k_proj", "attention.q_proj")
+
+    def __init__(self, state_dict, device):
+        lib = _lib.load()
+        srcs = []
+        for k in self.KEYS:
+            srcs.append(_f32(state_dict[k + ".weight"]).to(device))
+            srcs.append(_f32(state_dict[k + ".bias"]).to(device))
+        self._srcs = srcs
+        self.buffer = torch.empty(lib.sixdgs_packed_weights_floats(), device=device)
+        self.struct = ScorerWeights()
+        check(lib.sixdgs_pack_weights(*[_p(t) for t in srcs], _p(self.buffer), C.byref(self.struct), _stream()), "pack_weights")
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def ray_encode(ori, dr, rgb) -> torch.Tensor:
+    ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
+    _need_gpu(ori, dr, rgb)
+    x = torch.empty(ori.shape[0], RAY_IN_PAD, device=ori.device)
+    check(_lib.load().sixdgs_ray_encode(_p(ori), _p(dr), _p(rgb), ori.shape[0], _p(x), _stream()), "ray_encode")
+    return x
+
+
+def linear(x, w, b=None, relu: bool = False) -> torch.Tensor:
+    x, w = _f32(x), _f32(w)
+    _need_gpu(x, w)
+    b = _f32(b) if b is not None else None
+    y = torch.empty(x.shape[0], w.shape[0], device=x.device)
+    check(_lib.load().sixdgs_linear(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(w), w.stride(0), _p(b), w.shape[0], int(relu),
+                                    _p(y), y.stride(0), _stream()), "linear")
+    return y
+
+
+def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
+             workspace: Optional[torch.Tensor] = None):
+    ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
+    _need_gpu(ori, dr, rgb)
+    lib = _lib.load()
+    r = ori.shape[0]
+    dev = ori.device
+    feat = torch.empty(r, D, device=dev) if want_feat else None
+    key = torch.empty(r, D, device=dev) if want_key else None
+    nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
+    ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.sixdgs_ray_keys(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(ws), ws.numel(), _stream()),
+          "ray_keys")
+    return feat, key
+
+
+def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """list of [T_i, 398] -> tokens [B,256,398] (zero padded), n_tok int32 [B]."""
+    b = len(token_list)
+    tok = torch.zeros(b, MAX_TOKENS, TOK_IN, device=device)
+    n = torch.empty(b, dtype=torch.int32)
+    for i, t in enumerate(token_list):
+        if t.shape[0] > MAX_TOKENS or t.shape[1] != TOK_IN:
+            raise RuntimeError(f"6dgs_amd: token block {tuple(t.shape)} does not fit [<=256, 398]")
+        tok[i, : t.shape[0]] = t
+        n[i] = t.shape[0]
+    return tok, n.to(device)
+
+
+def q_proj(tokens: torch.Tensor, n_tok: torch.Tensor, weights: PackedWeights) -> torch.Tensor:
+    tokens = _f32(tokens)
+    _need_gpu(tokens, n_tok)
+    b = tokens.shape[0]
+    q = torch.empty(b, MAX_TOKENS, D, device=tokens.device)
+    check(_lib.load().sixdgs_q_proj(_p(tokens), _p(n_tok), b, weights.ref, _p(q), _stream()), "q_proj")
+    return q
+
+
+def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100) -> int:
+    return int(_lib.load().sixdgs_score_topk_workspace_bytes(int(r), int(batch), int(topk)))
+
+
+def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: int = 100, want_scores: bool = True,
+               want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
+    q, key = _f32(q), _f32(key)
+    _need_gpu(q, key, n_tok)
+    lib = _lib.load()
+    b, r, dev = q.shape[0], key.shape[0], q.device
+    idx = torch.empty(b, topk, dtype=torch.int64, device=dev)
+    val = torch.empty(b, topk, device=dev)
+    scores = torch.empty(b, r, device=dev) if want_scores else None
+    stats = torch.empty(b, MAX_TOKENS, 2, device=dev) if want_stats else None
+    if workspace is None:
+        inflight = b if images_in_flight is None else max(1, min(b, images_in_flight))
+        workspace = torch.empty(score_topk_workspace_bytes(r, inflight, topk), dtype=torch.uint8, device=dev)
+    check(lib.sixdgs_score_topk(_p(q), _p(n_tok), b, _p(key), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
+                                _p(workspace), workspace.numel(), _stream()), "score_topk")
+    return idx, val, scores, stats
+
+
+def topk(scores: torch.Tensor, k: int = 100):
+    scores = _f32(scores)
+    _need_gpu(scores)
+    lib = _lib.load()
+    s2 = scores.reshape(-1, scores.shape[-1])
+    b, r = s2.shape
+    idx = torch.empty(b, k, dtype=torch.int64, device=s2.device)
+    val = torch.empty(b, k, device=s2.device)
+    ws = torch.empty(lib.sixdgs_topk_workspace_bytes(r, b, k), dtype=torch.uint8, device=s2.device)
+    check(lib.sixdgs_topk(_p(s2), r, b, int(k), _p(idx), _p(val), _p(ws), ws.numel(), _stream()), "topk")
+    return idx.reshape(*scores.shape[:-1], k), val.reshape(*scores.shape[:-1], k)
+
+
+# ---------------------------------------------------------------------------------------------
+# pose
+# ---------------------------------------------------------------------------------------------
+def solve_pose(rays_ori, rays_dir, idx, val, up, gt_c2w=None):
+    """Batched pose tail.  idx/val [B,k], up [B,3], gt_c2w [B,4,4] or None.
+    Returns dict(c2w[B,4,4], status[B], w_final[B,k], n_kept[B], centre[B,3], errors[B,2])."""
+    rays_ori, rays_dir, val, up = _f32(rays_ori), _f32(rays_dir), _f32(val), _f32(up)
+    idx = _i64(idx)
+    _need_gpu(rays_ori, rays_dir, idx, val, up)
+    b, k = idx.shape
+    dev = idx.device
+    gt = _f32(gt_c2w) if gt_c2w is not None else None
+    c2w = torch.empty(b, 4, 4, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    wf = torch.empty(b, k, device=dev)
+    nk = torch.empty(b, dtype=torch.int32, device=dev)
+    ctr = torch.empty(b, 3, device=dev)
+    err = torch.empty(b, 2, device=dev)
+    check(_lib.load().sixdgs_solve_pose(_p(rays_ori), _p(rays_dir), rays_ori.shape[0], _p(idx), _p(val), k, _p(up), _p(gt), b,
+                                        _p(c2w), _p(status), _p(wf), _p(nk), _p(ctr), _p(err), _stream()), "solve_pose")
+    return dict(c2w=c2w, status=status, w_final=wf, n_kept=nk, centre=ctr, errors=err)

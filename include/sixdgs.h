@@ -1,0 +1,200 @@
+/*
+ * sixdgs.h -- C ABI of the MI355X-native 6DGS pose-estimation hot path (lib6dgs_hip.so).
+ *
+ * The reference (mbortolon97/6dgs) has NO FFI on this path: it is pure Python/PyTorch behind three
+ * callables (generate_all_possible_rays, IdentificationModule.test_image, test_pose_estimation).
+ * This header is the boundary a maintainer would bind from those callables (ctypes stub shown in
+ * INTEGRATION.md); every entry point names the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (the PyTorch caching allocator in
+ *    the shipped host shim) unless the name starts with h_; the library allocates nothing
+ *    persistent and keeps no mutable global state;
+ *  - all tensors are fp32 row-major contiguous, indices int64, masks uint8, as in the reference;
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and re-entrant;
+ *  - scratch memory comes from the caller: query *_workspace_bytes, pass `ws` (256-B aligned);
+ *  - return value: 0 = ok, <0 = SIXDGS_E_* argument error, >0 = hipError_t of a failed launch.
+ *    No exceptions cross the ABI.  The Python shim raises RuntimeError on non-zero (the only
+ *    exception type the reference driver catches, pretrain_eval_attention.py:243-244);
+ *  - ragged outputs are written into caller-sized buffers and their length is returned through a
+ *    device int64 (the caller syncs to read it, as the reference does at sampling.py:145).
+ */
+#ifndef SIXDGS_H
+#define SIXDGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIXDGS_ABI_VERSION 1
+#define SIXDGS_E_BADARG (-1)
+#define SIXDGS_E_WORKSPACE (-2)
+#define SIXDGS_E_UNSUPPORTED (-3)
+
+#define SIXDGS_D 384        /* embed dim (backbone.py:17, identification_module.py:44-46) */
+#define SIXDGS_RAY_IN 141   /* RayPreprocessor input width (ray_preprocessor.py:15) */
+#define SIXDGS_RAY_IN_PAD 144
+#define SIXDGS_HID 512      /* featureC (identification_module.py:16-18) */
+#define SIXDGS_TOK_IN 398   /* img_num_features + 14 (identification_module.py:20) */
+#define SIXDGS_MAX_TOKENS 256
+
+typedef void* sixdgs_stream_t;
+
+int sixdgs_abi_version(void);
+const char* sixdgs_error_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene-side geometry (once per scene) -- replaces pose_estimation/sampling.py:127-267
+ * ------------------------------------------------------------------------------------------- */
+
+/* a2: mask_degraded_ellipsoids (quadricell.py:171-188) on scale = exp(log_scale)
+ * (scene/gaussian_model.py:125-127).  mask[i] = total_rings(i) < target_points. */
+int sixdgs_mask_degraded(const float* log_scale /*[N,3]*/, int64_t n, int target_points, uint8_t* mask /*[N]*/,
+                         sixdgs_stream_t stream);
+
+/* a5: sym_eig_3x3 (sym_eig_3x3.py:246-307), eigenvectors in the columns of vecs (may be NULL). */
+int sixdgs_sym_eig_3x3(const float* mats /*[n,3,3]*/, int64_t n, float* vals /*[n,3]*/, float* vecs /*[n,3,3]*/,
+                       sixdgs_stream_t stream);
+
+/* a4: compute_normals (sampling.py:62-113): k nearest neighbours of each query in `cloud` (self
+ * included), centred scatter matrix, smallest-eigenvalue eigenvector, sign by majority vote.
+ * Brute force, exact; ties in distance -> lowest index.  knn (may be NULL) receives the neighbour
+ * indices sorted by distance.  k <= 32. */
+int sixdgs_normals_knn(const float* query /*[nq,3]*/, int64_t nq, const float* cloud /*[E,3]*/, int64_t e, int k,
+                       float* normals /*[nq,3]*/, int64_t* knn /*[nq,k] or NULL*/, sixdgs_stream_t stream);
+
+/* a1+a6+a7+a10, quadricell emitter (quadricell.py:191-386 with direction_mode="isocell", SH colour
+ * sampling.py:116-124,225-251).  Ellipsoid j of the emission set is Gaussian sel[j] (sel == NULL:
+ * j itself); its rays are written contiguously in ellipsoid -> ring -> cell order.
+ *   phase 1 (count): d_counts[j] = rays kept for ellipsoid j, d_offsets[j] = exclusive prefix,
+ *                    d_total[0] = total rays, d_total[1] = total cells before the hemisphere mask;
+ *   phase 2 (write): fills ori/dir/rgb/src (src = Gaussian index of each ray) using d_offsets.
+ * f_dc [N,1,3] and f_rest [N,ncoef-1,3] are the raw SH tensors (gaussian_model.py:146-150).
+ * `normals` [E,3] are per emission-set ellipsoid. */
+/* `scale` is [N,3]: the raw log-scales of the 3DGS checkpoint when scale_is_log != 0 (the kernel
+ * applies exp, gaussian_model.py:125-127), already-activated semi axes otherwise. */
+int sixdgs_emit_quadricell_count(const float* xyz, const float* scale, int scale_is_log, const float* rot,
+                                 const int64_t* sel, int64_t e, const float* normals, int target_points,
+                                 int table_res, int64_t* d_counts /*[E]*/, int64_t* d_offsets /*[E]*/,
+                                 int64_t* d_total /*[2]*/, sixdgs_stream_t stream);
+int sixdgs_emit_quadricell_write(const float* xyz, const float* scale, int scale_is_log, const float* rot,
+                                 const float* f_dc, const float* f_rest, int sh_degree, int n_coef,
+                                 const int64_t* sel, int64_t e, const float* normals, int target_points,
+                                 int table_res, const int64_t* d_offsets, float* ori, float* dir, float* rgb,
+                                 int64_t* src, sixdgs_stream_t stream);
+/* a6 alone (cell centres in the local frame + ellipsoid id), used by the parity tests:
+ * count -> d_counts/d_offsets/d_total[0]; then centres. */
+int sixdgs_quadricell_cell_counts(const float* scale /*[E,3] activated*/, int64_t e, int target_points,
+                                  int64_t* d_counts, int64_t* d_offsets, int64_t* d_total, sixdgs_stream_t stream);
+int sixdgs_quadricell_centers(const float* scale /*[E,3] activated*/, int64_t e, int target_points, int table_res,
+                              const int64_t* d_cell_offsets /*[E]*/, float* points, int64_t* ellipsoid_id,
+                              sixdgs_stream_t stream);
+
+/* a8: isocell_distribution(ray_target, N0, isrand=-1) (isocell.py:6-84).  Returns the number of
+ * directions N0*ceil(sqrt(target/N0))^2 via *h_count when dirs == NULL. */
+int sixdgs_isocell_distribution(int ray_target, int n0, float* dirs /*[K,3]*/, int64_t* h_count,
+                                sixdgs_stream_t stream);
+/* a9: rotate_isocell (isocell.py:171-222): out[e][k] = Rodrigues(z -> normal_e) * dirs[k];
+ * NaN when the normal is (anti)parallel to z, as the reference. */
+int sixdgs_rotate_isocell(const float* dirs, int64_t k, const float* normals, int64_t e, float* out /*[E,K,3]*/,
+                          sixdgs_stream_t stream);
+/* iso-cell emitter for "every Gaussian" mode (BASELINE.json configs "64/256 isocell rays per
+ * ellipsoid"; not on the reference's live path): ray (j,k): dir = rotate_isocell(dirs[k], n_j),
+ * ori = centre_j + the ellipsoid surface point along dir, rgb = SH colour at -dir.  E*K rays. */
+int sixdgs_emit_isocell(const float* xyz, const float* scale, int scale_is_log, const float* rot, const float* f_dc,
+                        const float* f_rest, int sh_degree, int n_coef, const int64_t* sel, int64_t e,
+                        const float* normals, const float* dirs, int64_t k, float* ori, float* dir, float* rgb,
+                        int64_t* src, sixdgs_stream_t stream);
+/* a10 alone: evaluate_viewdirs_color (sampling.py:116-124) for sh [R,3,ncoef] */
+int sixdgs_eval_sh_color(const float* sh, int n_coef, const float* dirs, int64_t r, int sh_degree, float* rgb,
+                         sixdgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scorer, scene side (once per scene): ray MLP + k_proj -> key cache
+ * replaces RayPreprocessor.forward (ray_preprocessor.py:36-46) + k_proj (our_multihead_attention.py:74)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sixdgs_scorer_weights {
+  /* padded copies prepared once by sixdgs_pack_weights (zero padding keeps the arithmetic exact) */
+  const float* w1; /* [512][144]  mlp.0  (cols 141..143 zero) */
+  const float* b1; /* [512] */
+  const float* w2; /* [512][512]  mlp.2 */
+  const float* b2;
+  const float* w3; /* [512][656]  mlp2.0 (cols 653..655 zero) */
+  const float* b3;
+  const float* w4; /* [384][512]  mlp2.2 */
+  const float* b4;
+  const float* wk; /* [384][384]  attention.k_proj */
+  const float* bk;
+  const float* wq; /* [384][400]  attention.q_proj (cols 398,399 zero) */
+  const float* bq;
+} sixdgs_scorer_weights;
+
+size_t sixdgs_packed_weights_floats(void);
+/* Packs the reference state_dict tensors (SURVEY.md §8(b) shapes) into one caller buffer and fills
+ * `out` with pointers into it. */
+int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* mlp2_w, const float* mlp2_b,
+                        const float* mlp2_0_w, const float* mlp2_0_b, const float* mlp2_2_w, const float* mlp2_2_b,
+                        const float* kproj_w, const float* kproj_b, const float* qproj_w, const float* qproj_b,
+                        float* packed, sixdgs_scorer_weights* out, sixdgs_stream_t stream);
+
+/* a12: x[R,144] = [pts, dir, rgb, PE(pts,8), PE(dir,8), PE(rgb,6), 0,0,0] */
+int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int64_t r, float* x, sixdgs_stream_t stream);
+
+/* a13 + k_proj.  feat (may be NULL) receives the [R,384] ray features, key the [R,384] keys.
+ * Rays are processed in chunks sized by the workspace (any ws >= the minimum works). */
+size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk);
+int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
+                    float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+
+/* generic fp32 MFMA GEMM used by the above: y[M,N] = act(x[M,K] . w[N,K]^T + b), K % 16 == 0,
+ * N % 128 == 0, ldx/ldw/ldy in floats and multiples of 4. */
+int sixdgs_linear(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
+                  int relu, float* y, int64_t ldy, sixdgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scorer, image side (per batch of query images)
+ * replaces MultiHeadAttention.forward (our_multihead_attention.py:70-79, 4-12),
+ * IdentificationModule.run_attention's column sum (identification_module.py:80-82) and
+ * torch.topk (identification_module.py:131)
+ * ------------------------------------------------------------------------------------------- */
+/* q[b] = tokens[b] . Wq^T + bq.  tokens [B, 256, 398] (rows >= n_tok[b] ignored), q [B,256,384]
+ * (rows >= n_tok[b] are written as zeros).  d_n_tok: device int32 [B], 0 <= n_tok <= 256. */
+int sixdgs_q_proj(const float* tokens, const int32_t* d_n_tok, int batch,
+                  const sixdgs_scorer_weights* w, float* q, sixdgs_stream_t stream);
+
+/* scores[b][r] = sum_t softmax_r(q[b][t] . key[r] / sqrt(384)); idx/val = top-k (sorted
+ * descending, ties -> lowest index).  scores may be NULL (then they live only in the workspace).
+ * Never materialises more than `ws` allows: images are processed in groups that fit. */
+size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk);
+int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, int batch, const float* key /*[R,384]*/,
+                      int64_t r, int topk, float* scores /*[B,R] or NULL*/, int64_t* idx /*[B,topk]*/,
+                      float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,
+                      size_t ws_bytes, sixdgs_stream_t stream);
+/* top-k alone over precomputed scores [B,R] */
+size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
+int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,
+                size_t ws_bytes, sixdgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pose assembly (per image) -- replaces pose_estimation/test.py:157-198,216-218 with
+ * line_intersection.py:5-34,75-154 and error_computation.py:3-8
+ * ------------------------------------------------------------------------------------------- */
+/* For each image b: duplicate-origin filter, unweighted LS centre (NaN when det < 1e-7),
+ * exclude_negatives reweighting, watch direction, make_rotation_mat(-watch, up[b]), singular -> I,
+ * c2w = [inv(R) | centre], NaN -> I4.
+ * outputs: c2w [B,4,4]; status [B] bit0 = singular rotation, bit1 = NaN pose (identity returned),
+ * bit2 = NaN centre; w_final [B,k] (0 for filtered rays), n_kept [B]; errors [B,2] =
+ * (translation error, angular error in degrees) against gt_c2w when gt_c2w != NULL. */
+int sixdgs_solve_pose(const float* rays_ori, const float* rays_dir, int64_t r, const int64_t* idx /*[B,k]*/,
+                      const float* val /*[B,k]*/, int k, const float* up /*[B,3]*/, const float* gt_c2w /*[B,4,4]*/,
+                      int batch, float* c2w, int32_t* status, float* w_final, int32_t* n_kept, float* centre /*[B,3]*/,
+                      float* errors, sixdgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIXDGS_H */

@@ -1,0 +1,362 @@
+"""GPU parity tests: every entry point of the C ABI (through 6dgs_amd.ops) against the CPU oracle and the
+reference-generated golden vectors, on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances are stated per test.  Integer / index / boolean results must be identical except at the
+documented floating-point tie boundaries (arc-length table look-ups within one ulp of an entry).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import quadricell_tie_cells, rel_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("6dgs_amd.ops")
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_library_is_the_hip_extension(ops):
+    lib = importlib.import_module("6dgs_amd._lib")
+    assert lib.load().sixdgs_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "lib6dgs_hip.so" in f.read()
+
+
+def test_a2_mask_degraded(ops, oracle, golden):
+    g = golden("g1_quadricell")
+    m = N(ops.mask_degraded(G(np.log(g["a2_scale"]))))
+    # exp(log(s)) differs from s by an ulp or two; compare against the oracle on the SAME activated values
+    act = np.exp(np.log(g["a2_scale"]).astype(np.float32)).astype(np.float32)
+    ref = oracle.mask_degraded(act)
+    assert (m != ref).sum() <= 2
+    assert (m != g["a2_mask"]).sum() <= 4
+
+
+def test_a5_sym_eig(ops, oracle, golden):
+    g = golden("g2_normals")
+    vals, vecs = ops.sym_eig_3x3(G(g["mats"]))
+    ov, oe = oracle.sym_eig_3x3(g["mats"])
+    nspd = 200
+    scale = np.abs(ov[:nspd]).max(1, keepdims=True)
+    assert (np.abs(N(vals)[:nspd] - ov[:nspd]) / scale).max() < 2e-5
+    gap = np.minimum(ov[:nspd, 1] - ov[:nspd, 0], ov[:nspd, 2] - ov[:nspd, 1]) / scale[:, 0]
+    ok = gap > 1e-2
+    assert np.abs(N(vecs)[:nspd][ok] - oe[:nspd][ok]).max() < 2e-3
+    assert np.abs(N(vecs)[:nspd][ok] - g["eigvecs"][:nspd][ok]).max() < 2e-3
+
+
+def test_a4_normals_knn(ops, oracle, golden):
+    g = golden("g2_normals")
+    n, knn = ops.normals_knn(G(g["pts"]), G(g["pts"]), 20, return_knn=True)
+    on, oknn = oracle.compute_normals(g["pts"], g["pts"], 20, return_knn=True)
+    assert (N(knn) == oknn).all()                     # same distances, same tie rule -> identical lists
+    assert np.abs(N(n) - on).max() < 2e-4
+    same = np.array([set(a) == set(b) for a, b in zip(N(knn), g["knn"])])
+    assert same.mean() > 0.99
+    assert np.abs(N(n)[same] - g["normals"][same]).max() < 5e-4
+
+
+def test_a4_normals_knn_chunked_queries(ops, oracle):
+    rng = np.random.default_rng(3)
+    cloud = rng.standard_normal((2500, 3)).astype(np.float32)
+    q = cloud[100:900]
+    n = ops.normals_knn(G(q), G(cloud), 20)
+    assert np.abs(N(n) - oracle.compute_normals(q, cloud, 20)).max() < 5e-4
+
+
+@pytest.mark.parametrize("P", [50, 64, 256])
+def test_a6_quadricell_centers(ops, oracle, golden, P):
+    g = golden("g1_quadricell")
+    pts, eid = ops.quadricell_centers(G(g["scale"]), P)
+    ref = g[f"P{P}_points"]
+    assert tuple(pts.shape) == ref.shape
+    assert (N(eid) == g[f"P{P}_eid"]).all()
+    d = np.abs(N(pts) - ref).max(1)
+    assert np.abs(N(pts)[:, 2] - ref[:, 2]).max() < 1e-7
+    ties = quadricell_tie_cells(g[f"P{P}_eid"], ref)       # exact ties of the reference's table: see conftest
+    assert (d[~ties] < 1e-6).all(), int((d[~ties] >= 1e-6).sum())
+    smax = g["scale"][g[f"P{P}_eid"]].max(1)
+    assert (d[ties] <= 2.5 * (2 * np.pi / 999) * smax[ties]).all()
+
+
+@pytest.mark.parametrize("P", [50, 64, 256])
+def test_a1_a6_a7_a10_emit_quadricell(ops, oracle, golden, syn, P):
+    """Full emitter on the g1 ellipsoids (activated scales passed directly): ray set identical to the
+    reference's, values within 1e-6 except the documented table ties."""
+    g = golden("g1_quadricell")
+    E = g["scale"].shape[0]
+    rng = np.random.default_rng(9)
+    f_dc = (0.3 * rng.standard_normal((E, 1, 3))).astype(np.float32)
+    f_rest = (0.3 * rng.standard_normal((E, 15, 3))).astype(np.float32)
+    ori, dr, rgb, src, n_cells = ops.emit_quadricell(G(g["xyz"]), G(g["scale"]), G(g["rot"]), G(f_dc), G(f_rest), 3, None,
+                                                     G(g["normals"]), P, scale_is_log=False)
+    assert n_cells == g[f"P{P}_points"].shape[0]
+    ref_ori, ref_dir, ref_mid = g[f"P{P}_ori"], g[f"P{P}_dir"], g[f"P{P}_mid"]
+    assert ori.shape[0] == ref_ori.shape[0]
+    assert (N(src) == ref_mid).all()
+    d = np.maximum(np.abs(N(ori) - ref_ori).max(1), np.abs(N(dr) - ref_dir).max(1) * g["scale"][ref_mid].max(1))
+    # map the tie mask of the cells onto the rays that survived the hemisphere mask (order preserved)
+    Rm = g["rotmat"][g[f"P{P}_eid"]]
+    pw = np.einsum("nij,nj->ni", Rm, g[f"P{P}_points"])
+    kept = g["normals"][g[f"P{P}_eid"], 0] * pw[:, 0] > 0
+    assert kept.sum() == ref_ori.shape[0]
+    ties = quadricell_tie_cells(g[f"P{P}_eid"], g[f"P{P}_points"])[kept]
+    assert (d[~ties] < 2e-6).all(), int((d[~ties] >= 2e-6).sum())
+    # colour: oracle SH on the emitted directions with the per-ray coefficients
+    sh = np.concatenate([f_dc, f_rest], 1).transpose(0, 2, 1)[N(src)]          # [R,3,16]
+    assert np.abs(N(rgb) - oracle.eval_sh_color(sh, N(dr), 3)).max() < 2e-6
+
+
+def test_emit_quadricell_subset_and_log_scale(ops, oracle, golden):
+    g = golden("g1_quadricell")
+    E = g["scale"].shape[0]
+    sel = np.array([5, 3, 40, 17, 17, 0], np.int64)
+    nrm = g["normals"][: len(sel)]
+    logs = np.log(g["scale"]).astype(np.float32)
+    ori, dr, rgb, src, _ = ops.emit_quadricell(G(g["xyz"]), G(logs), G(g["rot"]), None, None, 0, G(sel), G(nrm), 50,
+                                               scale_is_log=True, want_rgb=False)
+    act = np.exp(logs).astype(np.float32)
+    pts, eid = oracle.quadricell_centers(act[sel], 50)
+    o_ori, o_dir, o_mid = oracle.mask_and_compute_rays(pts, eid, nrm, g["xyz"][sel], oracle.build_rotation(g["rot"][sel]))
+    assert ori.shape[0] == o_ori.shape[0]
+    assert (N(src) == sel[o_mid]).all()
+    d = np.abs(N(ori) - o_ori).max(1)
+    Rm = oracle.build_rotation(g["rot"][sel])[eid]
+    kept = nrm[eid, 0] * np.einsum("nij,nj->ni", Rm, pts)[:, 0] > 0
+    ties = quadricell_tie_cells(eid, pts)[kept]            # only the structural table ties may differ
+    assert (d[~ties] < 2e-6).all()
+
+
+@pytest.mark.parametrize("tgt,n0", [(35, 3), (64, 1), (256, 1), (50, 1)])
+def test_a8_isocell_distribution(ops, golden, tgt, n0):
+    g = golden("g3_isocell")
+    d = N(ops.isocell_distribution(tgt, n0))
+    assert d.shape == g[f"dirs_{tgt}_{n0}"].shape
+    assert np.abs(d - g[f"dirs_{tgt}_{n0}"]).max() < 5e-7
+
+
+@pytest.mark.parametrize("tgt", [64, 256])
+def test_a9_rotate_isocell(ops, golden, tgt):
+    g = golden("g3_isocell")
+    r = N(ops.rotate_isocell(G(g[f"dirs_{tgt}_1"]), G(g["normals"])))
+    ref = g[f"rot_{tgt}"]
+    assert (np.isnan(r) == np.isnan(ref)).all()
+    assert np.nanmax(np.abs(r - ref)) < 1e-6
+
+
+def test_emit_isocell(ops, oracle, syn):
+    sc = syn.make_scene(500, 1)
+    rng = np.random.default_rng(2)
+    nrm = rng.standard_normal((500, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    dirs = ops.isocell_distribution(64, 1)
+    ori, dr, rgb, src = ops.emit_isocell(G(sc["xyz"]), G(sc["log_scale"]), G(sc["rot"]), G(sc["f_dc"]), G(sc["f_rest"]), 3, None,
+                                         G(nrm), dirs)
+    K = dirs.shape[0]
+    assert ori.shape[0] == 500 * K
+    ref_dir = oracle.rotate_isocell(N(dirs), nrm).reshape(-1, 3)
+    assert np.abs(N(dr) - ref_dir).max() < 1e-6
+    # origins lie on the ellipsoid surface along the ray direction from the centre
+    R = oracle.build_rotation(sc["rot"])
+    s = np.exp(sc["log_scale"])
+    off = (N(ori).reshape(500, K, 3) - sc["xyz"][:, None]).astype(np.float64)
+    loc = np.einsum("eji,ekj->eki", R.astype(np.float64), off)
+    assert np.abs(((loc / s[:, None]) ** 2).sum(-1) - 1).max() < 1e-4
+    cosang = (off * N(dr).reshape(500, K, 3)).sum(-1) / np.linalg.norm(off, axis=-1)
+    assert cosang.min() > 1 - 1e-5
+    sh = np.concatenate([sc["f_dc"], sc["f_rest"]], 1).transpose(0, 2, 1)[N(src)]
+    assert np.abs(N(rgb) - oracle.eval_sh_color(sh, N(dr), 3)).max() < 2e-6
+    assert (N(src).reshape(500, K) == np.arange(500)[:, None]).all()
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_a10_sh_colour(ops, golden, deg):
+    g = golden("g4_sh")
+    c = N(ops.eval_sh_color(G(g["sh"]), G(g["dir"]), deg))
+    assert np.abs(c - g[f"rgb_deg{deg}"]).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# scorer
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def scorer(ops, oracle, golden, syn):
+    g = golden("g5_scorer")
+    sd = syn.make_scorer_state_dict(0)
+    rays = syn.make_rays(4096, 0)
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
+    feat, key = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True)
+    ofeat, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
+    return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey)
+
+
+def test_a12_ray_encode(ops, oracle, scorer):
+    r = scorer["rays"]
+    x = N(ops.ray_encode(G(r["ori"]), G(r["dir"]), G(r["rgb"])))
+    ox = oracle.ray_input(r["ori"], r["dir"], r["rgb"])
+    assert x.shape == (4096, 144)
+    assert np.abs(x[:, :141] - ox).max() < 5e-7          # |arg| up to ~500: sin/cos within an ulp or two
+    assert (x[:, 141:] == 0).all()
+
+
+def test_linear_mfma_vs_fp64(ops):
+    """The fp32 MFMA tile kernel against an fp64 product, with an asymmetric weight matrix (catches
+    transposed fragments) and ragged M / K tails."""
+    rng = np.random.default_rng(0)
+    for m, k, n in ((300, 144, 512), (128, 656, 512), (1000, 384, 384), (77, 20, 128)):
+        x = rng.standard_normal((m, k)).astype(np.float32)
+        w = (rng.standard_normal((n, k)) * np.linspace(0.5, 2.0, n)[:, None]).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        y = N(ops.linear(G(x), G(w), G(b), relu=False))
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        assert rel_err(y, ref) < 2e-6, (m, k, n)
+        yr = N(ops.linear(G(x), G(w), G(b), relu=True))
+        assert rel_err(yr, np.maximum(ref, 0)) < 2e-6
+
+
+def test_a13_ray_features_and_keys(scorer):
+    g = scorer["g"]
+    assert rel_err(N(scorer["feat"]), scorer["ofeat"]) < 5e-6
+    assert rel_err(N(scorer["key"]), scorer["okey"]) < 5e-6
+    assert rel_err(N(scorer["feat"])[:128], g["feat_head"]) < 5e-6
+    assert rel_err(N(scorer["key"])[:128], g["key_head"]) < 5e-6
+
+
+def test_ray_keys_chunked_equals_unchunked(ops, scorer):
+    r = scorer["rays"]
+    ws = torch.empty(1000 * (144 + 512 + 512) * 4, dtype=torch.uint8, device="cuda")   # forces ~900-ray chunks
+    _, key2 = ops.ray_keys(G(r["ori"]), G(r["dir"]), G(r["rgb"]), scorer["w"], workspace=ws, max_chunk=1000)
+    assert torch.equal(key2, scorer["key"])
+
+
+@pytest.mark.parametrize("tag,T,scale", [("flat256", 256, 1.0), ("peaky256", 256, 40.0), ("peaky137", 137, 40.0),
+                                         ("mid1", 1, 10.0)])
+def test_a14_a15_score_topk(ops, oracle, scorer, syn, tag, T, scale):
+    g = scorer["g"]
+    tok = syn.make_tokens(T, 1, scale)
+    tokens, n_tok = ops.pad_tokens([G(tok)], "cuda")
+    q = ops.q_proj(tokens, n_tok, scorer["w"])
+    oq = oracle.q_proj(tok, scorer["sd"])
+    assert rel_err(N(q)[0, :T], oq) < 5e-6
+    assert (N(q)[0, T:] == 0).all()
+    idx, val, scores, stats = ops.score_topk(q, n_tok, scorer["key"], 100, want_stats=True)
+    s = N(scores)[0]
+    # values: 1e-5 relative against the reference's fp32 result and against the oracle
+    assert rel_err(s, g[f"{tag}_scores"]) < 1e-5
+    os_, omx, osm = oracle.attention_scores(oq, scorer["okey"], return_stats=True)
+    assert rel_err(s, os_) < 1e-5
+    assert np.abs(N(stats)[0, :T, 0] - omx).max() < 1e-4
+    assert rel_err(N(stats)[0, :T, 1], osm) < 1e-5
+    assert abs(float(s.astype(np.float64).sum()) - T) < 1e-3 * T
+    # top-k: exactly the kernel's own scores sorted (value desc, index asc) ...
+    order = np.lexsort((np.arange(s.size), -s))[:100]
+    assert (N(idx)[0] == order).all()
+    assert (N(val)[0] == s[order]).all()
+    # ... and the reference's index set wherever the fp64 gap exceeds 4x the fp32 error bound
+    s64 = g[f"{tag}_scores64"]
+    o64 = np.argsort(-s64)
+    must = set(o64[:100][s64[o64[:100]] - s64[o64[100]] > 4e-6 * s64[o64[0]]].tolist())
+    assert must <= set(N(idx)[0].tolist())
+    assert set(N(idx)[0].tolist()) == set(g[f"{tag}_idx"].tolist())
+    if tag != "flat256":
+        assert (N(idx)[0] == g[f"{tag}_idx"]).all()      # order too when the gaps are real
+
+
+def test_score_topk_batched_and_grouped(ops, scorer, syn):
+    """A batch with ragged token counts, processed (a) all at once and (b) one image at a time through a
+    workspace that only fits a single image -- identical results."""
+    toks = [syn.make_tokens(t, 10 + i, 40.0) for i, t in enumerate((256, 137, 1, 200, 0))]
+    tokens, n_tok = ops.pad_tokens([G(t) for t in toks], "cuda")
+    q = ops.q_proj(tokens, n_tok, scorer["w"])
+    idx, val, sc, _ = ops.score_topk(q, n_tok, scorer["key"], 100)
+    idx1, val1, sc1, _ = ops.score_topk(q, n_tok, scorer["key"], 100, images_in_flight=1)
+    assert torch.equal(idx, idx1) and torch.equal(val, val1) and torch.equal(sc, sc1)
+    for i in range(4):
+        qi = q[i:i + 1].contiguous()
+        ii, vi, si, _ = ops.score_topk(qi, n_tok[i:i + 1].contiguous(), scorer["key"], 100)
+        assert torch.equal(ii[0], idx[i]) and torch.equal(si[0], sc[i])
+    assert (N(sc)[4] == 0).all()                          # no tokens -> all-zero scores (empty sum)
+    assert (N(idx)[4] == np.arange(100)).all()            # all ties -> lowest indices
+
+
+def test_topk_ties_short_and_large(ops, oracle):
+    rng = np.random.default_rng(1)
+    # heavy ties
+    s = rng.integers(0, 7, size=(3, 5000)).astype(np.float32)
+    idx, val = ops.topk(G(s), 100)
+    for b in range(3):
+        oi, ov = oracle.topk(s[b], 100)
+        assert (N(idx)[b] == oi).all() and (N(val)[b] == ov).all()
+    # fewer elements than k: padded with (-1, NaN)
+    s = rng.standard_normal((2, 37)).astype(np.float32)
+    idx, val = ops.topk(G(s), 100)
+    for b in range(2):
+        oi, ov = oracle.topk(s[b], 100)
+        assert (N(idx)[b, :37] == oi).all() and (N(idx)[b, 37:] == -1).all() and np.isnan(N(val)[b, 37:]).all()
+    # negative, zero, large; multi-block
+    s = (rng.standard_normal((2, 300_000)) * 5).astype(np.float32)
+    s[0, 123456] = np.inf
+    idx, val = ops.topk(G(s), 100)
+    for b in range(2):
+        oi, ov = oracle.topk(s[b], 100)
+        assert (N(idx)[b] == oi).all() and (N(val)[b] == ov).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# pose tail
+# ------------------------------------------------------------------------------------------------
+def test_a17_to_a21_solve_pose(ops, oracle, golden):
+    g = golden("g6_pose")
+    cases = [str(c) for c in g["cases"]]
+    for name in cases:
+        k = g[f"{name}_idx"].shape[0]
+        out = ops.solve_pose(G(g[f"{name}_ori"]), G(g[f"{name}_dir"]), G(g[f"{name}_idx"])[None], G(g[f"{name}_w"])[None],
+                             G(g[f"{name}_up"])[None], G(g[f"{name}_gt"])[None])
+        keep = N(out["w_final"])[0] != 0
+        o = oracle.pose_from_topk(g[f"{name}_ori"], g[f"{name}_dir"], g[f"{name}_idx"], g[f"{name}_w"], g[f"{name}_up"])
+        assert int(out["n_kept"][0]) == int(g[f"{name}_keep_mask"].sum()), name
+        st = int(out["status"][0])
+        assert bool(st & 1) == bool(g[f"{name}_flags"][0]) and bool(st & 2) == bool(g[f"{name}_flags"][1]), name
+        assert np.abs(N(out["c2w"])[0] - g[f"{name}_c2w"]).max() < 1e-5, name
+        assert np.abs(N(out["c2w"])[0] - o["c2w"]).max() < 1e-5, name
+        if np.isnan(g[f"{name}_centre"]).any():
+            assert st & 4 and np.isnan(N(out["centre"])[0]).all()
+        else:
+            assert np.abs(N(out["centre"])[0] - g[f"{name}_centre"]).max() < 1e-5, name
+            # dropped rays have weight 0; kept-but-excluded ones too, so compare the dense vector
+            assert np.abs(N(out["w_final"])[0] - o["w_final"]).max() < 1e-7, name
+        assert abs(float(out["errors"][0, 0]) - float(g[f"{name}_terr"])) < 1e-5, name
+        assert abs(float(out["errors"][0, 1]) - float(g[f"{name}_aerr"])) < 1e-3, name
+        assert k <= 256 and keep.sum() <= k
+
+
+def test_solve_pose_batched_equals_single(ops, golden):
+    g = golden("g6_pose")
+    names = ["plain", "dups", "behind", "mixed"]
+    R = g["plain_ori"].shape[0]
+    # stack the four ray sets into one array and offset the indices
+    ori = np.concatenate([g[f"{n}_ori"] for n in names])
+    dr = np.concatenate([g[f"{n}_dir"] for n in names])
+    idx = np.stack([g[f"{n}_idx"] + i * R for i, n in enumerate(names)])
+    w = np.stack([g[f"{n}_w"] for n in names])
+    up = np.stack([g[f"{n}_up"] for n in names])
+    out = ops.solve_pose(G(ori), G(dr), G(idx), G(w), G(up))
+    for i, n in enumerate(names):
+        assert np.abs(N(out["c2w"])[i] - g[f"{n}_c2w"]).max() < 1e-5
+    assert np.isnan(N(out["errors"])).all()               # no ground truth given

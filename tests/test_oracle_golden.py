@@ -8,7 +8,7 @@ results are compared at ~1e-6 relative; integer/boolean/index results must be id
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import quadricell_tie_cells, rel_err
 
 
 def test_a1_rotation_matrices(oracle, golden):
@@ -33,12 +33,13 @@ def test_a6_quadricell_centers(oracle, golden, P):
     d = np.abs(pts - ref).max(1)
     # z (ring centre) has no transcendental: exact
     assert np.abs(pts[:, 2] - ref[:, 2]).max() < 1e-7
-    # arc-length lookup: a cell whose theta is within an ulp of a table entry may pick the
-    # neighbouring entry (one table step ~ 2*pi/999 rad).  Documented tie policy: <=0.2 % of cells.
-    flips = d > 1e-6
-    assert flips.mean() <= 2e-3, flips.sum()
+    # arc-length look-up: identical except at the exact mathematical ties of the reference's table
+    # (conftest.quadricell_tie_cells), where the pick may move by one table step (2*pi/999 rad)
+    ties = quadricell_tie_cells(eid, ref)
+    assert (d[~ties] < 1e-6).all()
     scale_max = g["scale"][eid].max(1)
-    assert (d[flips] <= 2.5 * (2 * np.pi / 999) * scale_max[flips]).all()
+    assert (d[ties] <= 2.5 * (2 * np.pi / 999) * scale_max[ties]).all()
+    assert ties.mean() < 0.1
 
 
 @pytest.mark.parametrize("P", [50, 64, 256])
