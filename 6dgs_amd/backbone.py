@@ -127,7 +127,7 @@ def create_backbone(type="dino", backbone: Optional[torch.nn.Module] = None, **k
         try:
             backbone = torch.hub.load("facebookresearch/dinov2", "dinov2_vits14")
         except Exception as e:  # offline: no network, no cache
-            warnings.warn(f"DINOv2 weights unavailable ({type(e).__name__}); using a randomly initialised ViT-S/14")
+            warnings.warn(f"DINOv2 weights unavailable ({e.__class__.__name__}); using a randomly initialised ViT-S/14")
             backbone = ViTS14()
     return backbone, (16, 16), 384
 

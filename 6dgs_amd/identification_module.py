@@ -1,0 +1,191 @@
+"""IdentificationModule -- drop-in for pose_estimation/identification_module.py:10-133.
+
+Same constructor, same parameter names (the reference's id_module.th["model_state_dict"] loads with
+load_state_dict), same test_image() return tuple.  The ray side (RayPreprocessor MLP + k_proj) and
+the attention scorer + top-k run in the HIP library; the DINOv2 backbone and the camera-up CNN stay
+on PyTorch-ROCm.
+
+Differences that make the path fast while keeping results:
+  * the ray features/keys depend only on (rays, weights): they are computed ONCE per scene and cached
+    (the reference recomputes the 1.7 MFLOP/ray MLP for every image, identification_module.py:79);
+  * the [T, R] attention map is never handed out as a dense tensor: test_image returns a shape-only
+    proxy (test.py:117 only reads .shape[-2]); `attention_map.materialize()` builds it on request;
+  * test_images() scores a whole batch of query images against one pass over the key cache.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .backbone import BackboneWrapper
+from .camera_direction_network import CameraDirectionPredictor
+
+
+class RayPreprocessor(torch.nn.Module):
+    """Parameter holder with the reference layout (ray_preprocessor.py:11-34)."""
+
+    def __init__(self, viewpe=8, pospe=8, rgbpe=6, featureC=128, fea_output=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 3 + 2 * pospe * 3 + 3 + 2 * rgbpe * 3 + 3
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(self.in_mlpC, featureC), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(featureC, featureC), torch.nn.ReLU(inplace=True))
+        self.mlp2 = torch.nn.Sequential(torch.nn.Linear(featureC + self.in_mlpC, featureC), torch.nn.ReLU(inplace=True),
+                                        torch.nn.Linear(featureC, fea_output))
+        self.viewpe, self.pospe, self.rgbpe = viewpe, pospe, rgbpe
+
+
+class MultiHeadAttention(torch.nn.Module):
+    """Parameter holder (our_multihead_attention.py:46-68): q_proj 398->384, k_proj 384->384."""
+
+    def __init__(self, ray_fea_size, img_fea_size, embed_dim, num_heads=1):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.q_proj = torch.nn.Linear(img_fea_size, embed_dim)
+        self.k_proj = torch.nn.Linear(ray_fea_size, embed_dim)
+        torch.nn.init.xavier_uniform_(self.q_proj.weight)
+        self.q_proj.bias.data.fill_(0)
+        torch.nn.init.xavier_uniform_(self.k_proj.weight)
+        self.k_proj.bias.data.fill_(0)
+
+
+class AttentionMapProxy:
+    """Stands in for the dense softmax(QK^T) [T, R] map (32 GB at R = 32 M)."""
+
+    def __init__(self, n_tokens: int, n_rays: int, builder=None):
+        self.shape = torch.Size((n_tokens, n_rays))
+        self._builder = builder
+
+    def materialize(self) -> torch.Tensor:
+        if self._builder is None:
+            raise RuntimeError("attention map not retained")
+        return self._builder()
+
+
+class IdentificationModule(torch.nn.Module):
+    def __init__(self, backbone_type: str = "dino", camera_up_output_augmentation=None,
+                 target_rays_dirs: Optional[torch.Tensor] = None, augmentation_channels: int = 10,
+                 backbone: Optional[torch.nn.Module] = None):
+        super().__init__()
+        if camera_up_output_augmentation not in (None, 0, "NONE") and getattr(camera_up_output_augmentation, "name", "NONE") != "NONE":
+            raise NotImplementedError("camera-up output augmentations are not on the accelerated path "
+                                      "(reference default is NONE, identification_module.py:11,35-36)")
+        self.backbone_wrapper = BackboneWrapper(backbone_type=backbone_type, backbone=backbone)
+        nf = self.backbone_wrapper.img_num_features
+        self.ray_preprocessor = RayPreprocessor(featureC=512, fea_output=nf)
+        self.camera_up_out_augmentation = None
+        self.camera_direction_prediction_network = CameraDirectionPredictor(nf, self.backbone_wrapper.backbone_wh, fea_output=3)
+        self.attention = MultiHeadAttention(nf, nf + 14, nf, 1)
+        self._packed = None
+        self._packed_key = None
+        self._key_cache = None
+        self._key_cache_id = None
+
+    # ---- caches -------------------------------------------------------------------------------------
+    def _scorer_params(self):
+        rp, at = self.ray_preprocessor, self.attention
+        return {
+            "ray_preprocessor.mlp.0.weight": rp.mlp[0].weight, "ray_preprocessor.mlp.0.bias": rp.mlp[0].bias,
+            "ray_preprocessor.mlp.2.weight": rp.mlp[2].weight, "ray_preprocessor.mlp.2.bias": rp.mlp[2].bias,
+            "ray_preprocessor.mlp2.0.weight": rp.mlp2[0].weight, "ray_preprocessor.mlp2.0.bias": rp.mlp2[0].bias,
+            "ray_preprocessor.mlp2.2.weight": rp.mlp2[2].weight, "ray_preprocessor.mlp2.2.bias": rp.mlp2[2].bias,
+            "attention.k_proj.weight": at.k_proj.weight, "attention.k_proj.bias": at.k_proj.bias,
+            "attention.q_proj.weight": at.q_proj.weight, "attention.q_proj.bias": at.q_proj.bias,
+        }
+
+    def packed_weights(self, device) -> ops.PackedWeights:
+        params = self._scorer_params()
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._packed is None or self._packed_key != key:
+            self._packed = ops.PackedWeights(params, device)
+            self._packed_key = key
+            self._key_cache = None
+        return self._packed
+
+    def ray_keys(self, rays_ori, rays_dir, rays_rgb) -> torch.Tensor:
+        """K[R,384] = k_proj(RayPreprocessor(rays)) -- cached per (ray tensors, weights)."""
+        w = self.packed_weights(rays_ori.device)
+        ident = (rays_ori.data_ptr(), rays_dir.data_ptr(), rays_rgb.data_ptr(), rays_ori.shape[0], rays_ori._version,
+                 rays_dir._version, rays_rgb._version, self._packed_key)
+        if self._key_cache is None or self._key_cache_id != ident:
+            _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w)
+            self._key_cache, self._key_cache_id = key, ident
+        return self._key_cache
+
+    def ray_features(self, rays_ori, rays_dir, rays_rgb) -> torch.Tensor:
+        """RayPreprocessor.forward (ray_preprocessor.py:36-46): [R,384] features (not cached)."""
+        feat, _ = ops.ray_keys(rays_ori, rays_dir, rays_rgb, self.packed_weights(rays_ori.device), want_feat=True, want_key=False)
+        return feat
+
+    def invalidate_caches(self):
+        self._packed = self._key_cache = None
+
+    # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
+    @torch.no_grad()
+    def image_tokens(self, imgs: Sequence[torch.Tensor], masks: Sequence[torch.Tensor]):
+        """Batch of images (any sizes) -> list of (tokens+pe [T,398], fmap [384,16,16])."""
+        bw = self.backbone_wrapper
+        pre = [bw.preprocess(i, m) for i, m in zip(imgs, masks)]
+        feats = bw.features_from_norm(torch.cat([p[0] for p in pre], dim=0))
+        toks, fmaps = [], []
+        for f, (_, mimg) in zip(feats, pre):
+            t_pe, _, fmap = bw.assemble(f, mimg)
+            toks.append(t_pe)
+            fmaps.append(fmap)
+        return toks, torch.stack(fmaps)
+
+    @torch.no_grad()
+    def camera_up(self, fmaps: torch.Tensor) -> torch.Tensor:
+        up = self.camera_direction_prediction_network(fmaps)
+        return torch.nn.functional.normalize(up, dim=-1)
+
+    # ---- scoring -----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def score_tokens(self, token_list: List[torch.Tensor], rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100,
+                     want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
+        """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
+        key = self.ray_keys(rays_ori, rays_dir, rays_rgb)
+        w = self.packed_weights(rays_ori.device)
+        tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
+        q = ops.q_proj(tokens, n_tok, w)
+        idx, val, scores, _ = ops.score_topk(q, n_tok, key, rays_to_output, want_scores=want_scores, workspace=workspace,
+                                             images_in_flight=images_in_flight)
+        return idx, val, scores
+
+    @torch.no_grad()
+    def test_images(self, imgs, masks, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, want_scores: bool = True,
+                    workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
+        """Batched test_image: returns dict(idx[B,k], values[B,k], scores[B,R]|None, camera_up_dir[B,3], n_tokens[B])."""
+        toks, fmaps = self.image_tokens(imgs, masks)
+        up = self.camera_up(fmaps)
+        idx, val, scores = self.score_tokens(toks, rays_ori, rays_dir, rays_rgb, rays_to_output, want_scores, workspace,
+                                             images_in_flight)
+        return dict(idx=idx, values=val, scores=scores, camera_up_dir=up, n_tokens=[int(t.shape[0]) for t in toks], tokens=toks)
+
+    @torch.no_grad()
+    def test_image(self, img: torch.Tensor, mask: torch.Tensor, rays_ori: torch.Tensor, rays_dir: torch.Tensor,
+                   rays_rgb: torch.Tensor, rays_to_output: int = 100):
+        """identification_module.py:117-133: (indices, values, scores, camera_up_dir, attention_map)."""
+        out = self.test_images([img], [mask], rays_ori, rays_dir, rays_rgb, rays_to_output)
+        tok = out["tokens"][0]
+
+        def build():
+            q = torch.nn.functional.linear(tok, self.attention.q_proj.weight, self.attention.q_proj.bias)
+            return torch.softmax((q @ self.ray_keys(rays_ori, rays_dir, rays_rgb).T) / (q.shape[-1] ** 0.5), dim=-1)
+
+        return (out["idx"][0], out["values"][0], out["scores"][0], out["camera_up_dir"][0],
+                AttentionMapProxy(tok.shape[0], rays_ori.shape[0], build))
+
+    def run_attention(self, img, mask, rays_ori, rays_dir, rays_rgb):
+        """identification_module.py:77-92 (inference): (score, attention_map, features_img_flat, camera_up_dir)."""
+        with torch.no_grad():
+            t_pe, t_flat, fmap = self.backbone_wrapper(img, mask)
+            _, _, scores = self.score_tokens([t_pe], rays_ori, rays_dir, rays_rgb, 1)
+            up = self.camera_up(fmap[None])[0]
+        return scores[0], AttentionMapProxy(t_pe.shape[0], rays_ori.shape[0]), t_flat, up
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("IdentificationModule.forward is the TRAINING path (randperm over rays, autograd through the "
+                                  "scorer; identification_module.py:94-115) -- out of scope of the inference build (SURVEY.md §8(f) #1)")

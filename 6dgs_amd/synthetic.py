@@ -145,10 +145,12 @@ def make_cameras(b: int, seed: int = 0, width: int = 800, height: int = 800, fov
     return cams
 
 
-def checksum(sd: Dict[str, np.ndarray]) -> float:
-    """Order-stable float64 checksum of a dict of arrays (guards against RNG stream drift)."""
-    tot = 0.0
+def checksum(sd: Dict[str, np.ndarray]) -> int:
+    """Exact (integer, order-independent) checksum of a dict of fp32 arrays -- guards the fixtures against a
+    drift of numpy's RNG streams.  Pure integer arithmetic, so it is identical on every host."""
+    tot = 0
     for k in sorted(sd):
-        a = np.asarray(sd[k], dtype=np.float64).ravel()
-        tot += float(np.dot(a, np.cos(np.arange(a.size, dtype=np.float64) * 1e-3)))
+        bits = np.frombuffer(np.ascontiguousarray(sd[k], dtype=np.float32).tobytes(), dtype=np.uint32).astype(np.uint64)
+        w = (np.arange(bits.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        tot = (tot + int((bits * w).sum(dtype=np.uint64))) % (1 << 61)
     return tot

@@ -272,7 +272,7 @@ def _load_scorer(m, sd_np):
 def g5(m):
     sd_np = syn.make_scorer_state_dict(0)
     idm = _load_scorer(m, sd_np)
-    out = {"sd_checksum": np.float64(syn.checksum(sd_np))}
+    out = {"sd_checksum": np.int64(syn.checksum(sd_np))}
     R = 4096
     rays = syn.make_rays(R, 0)
     ori, dr, rgb = T(rays["ori"]), T(rays["dir"]), T(rays["rgb"])
@@ -474,7 +474,7 @@ def g7(m):
     results, te, ae, _, _ = m["test"].test_pose_estimation(
         cams, idm, rays_ori, rays_dir, rays_rgb, torch.tensor([0.0, 1.0, 0.0]), loss_fn=None)
     out["e2e_q_scale"] = np.float32(40.0)
-    out["e2e_sd_checksum"] = np.float64(syn.checksum(sd_np))
+    out["e2e_sd_checksum"] = np.int64(syn.checksum(sd_np))
     for i, (r, c) in enumerate(zip(results, captured)):
         out[f"e2e{i}_tokens"] = c["tokens"]
         out[f"e2e{i}_up"] = c["up"]

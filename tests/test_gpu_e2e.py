@@ -1,0 +1,161 @@
+"""End-to-end GPU parity through the drop-in Python API (generate_all_possible_rays,
+IdentificationModule, test_pose_estimation) against the g7 fixtures, which were produced by running
+the reference's own functions on the same synthetic scene / weights / cameras."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import quadricell_tie_cells, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return importlib.import_module("6dgs_amd")
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["n3000_p50", "n400_p64"])
+def test_a11_generate_all_possible_rays(pkg, golden, syn, oracle, tag):
+    g = golden("g7_e2e")
+    n, P, seed = (int(v) for v in g[f"{tag}_meta"])
+    scene = pkg.GaussianScene.from_dict(syn.make_scene(n, seed))
+    ori, dr, rgb, src = pkg.generate_all_possible_rays(scene, sample_quadricell_targets=P, perm=G(g[f"{tag}_perm"]),
+                                                       return_src=True)
+    ref_ori, ref_dir, ref_rgb = g[f"{tag}_ori"], g[f"{tag}_dir"], g[f"{tag}_rgb"]
+    # The ray count depends on hemisphere-mask sign tests on kNN normals that went through a 3x3
+    # eigen-solve: identical except where n.x * p.x is within rounding of 0.  Compare ray sets per
+    # source Gaussian.
+    sc = syn.make_scene(n, seed)
+    assert abs(ori.shape[0] - ref_ori.shape[0]) <= max(2, int(2e-4 * ref_ori.shape[0]))
+    if ori.shape[0] == ref_ori.shape[0]:
+        d = np.abs(N(ori) - ref_ori).max(1)
+        smax = np.exp(sc["log_scale"])[N(src)].max(1)
+        # all but the structural table ties (<~6 % of cells are tie candidates, a few % of those flip)
+        assert (d > 5e-6).mean() < 5e-3
+        assert (d <= 5e-6 + 2.5 * (2 * np.pi / 999) * smax).all()
+        ok = d <= 5e-6
+        assert np.abs(N(dr)[ok] - ref_dir[ok]).max() < 5e-5
+        assert np.abs(N(rgb)[ok] - ref_rgb[ok]).max() < 5e-4
+    # same ellipsoids, same order
+    e_first = N(src)[np.concatenate([[True], N(src)[1:] != N(src)[:-1]])]
+    valid = np.nonzero(oracle.mask_degraded(np.exp(sc["log_scale"]).astype(np.float32)))[0]
+    assert (e_first == valid[g[f"{tag}_perm"][:1000]][: e_first.shape[0]]).all() or e_first.shape[0] <= min(1000, valid.shape[0])
+
+
+def test_generate_rays_default_subsample_and_full_modes(pkg, syn):
+    scene = pkg.GaussianScene.from_dict(syn.make_scene(5000, 2))
+    torch.manual_seed(0)
+    ori, dr, rgb = pkg.generate_all_possible_rays(scene)
+    assert 20_000 < ori.shape[0] < 40_000 and ori.shape == dr.shape == rgb.shape      # ~28.5 rays x 1000 ellipsoids
+    assert torch.isfinite(ori).all() and (rgb >= 0).all()
+    assert (dr.norm(dim=1) - 1).abs().max() < 1e-5
+    # every valid Gaussian, iso-cell emitter: exactly E*K rays
+    o2, d2, c2, src = pkg.generate_all_possible_rays(scene, max_ellipsoids=-1, emitter="isocell", rays_per_ellipsoid=64,
+                                                     return_src=True)
+    assert o2.shape[0] == 5000 * 64 and (torch.bincount(src) == 64).all()
+    finite = torch.isfinite(d2).all(dim=1)
+    assert finite.float().mean() > 0.999                 # NaN only for normals exactly (anti)parallel to z
+    assert ((d2[finite].norm(dim=1) - 1).abs() < 1e-4).all()
+
+
+@pytest.fixture(scope="module")
+def e2e(pkg, golden, syn):
+    g = golden("g7_e2e")
+    sd_np = syn.make_scorer_state_dict(0, with_cnn=True)
+    assert syn.checksum(sd_np) == int(g["e2e_sd_checksum"])
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    with torch.no_grad():
+        idm.attention.q_proj.weight.mul_(float(g["e2e_q_scale"]))
+    idm = idm.cuda().eval()
+    cams = syn.make_cameras(3, 7, width=96, height=96, rgba=False) + syn.make_cameras(1, 8, width=80, height=80, rgba=True)
+    cams = [pkg.CameraInfo(**c) for c in cams]
+    return g, idm, cams
+
+
+def test_a22_camera_up_cnn_mirror(e2e):
+    g, idm, _ = e2e
+    n = int(g["e2e_n"])
+    fm = torch.stack([G(g[f"e2e{i}_fmap"]) for i in range(n)])
+    up = N(idm.camera_up(fm))
+    ref = np.stack([g[f"e2e{i}_up"] for i in range(n)])
+    assert np.abs(up - ref).max() < 2e-4     # MIOpen conv vs the CPU reference, fp32
+
+
+def test_a16_image_prep_matches_reference_semantics(pkg, e2e):
+    tp = importlib.import_module("6dgs_amd.test")
+    _, _, cams = e2e
+    img, mask = tp.prepare_image(cams[3].image, "cuda")         # RGBA
+    a = np.asarray(cams[3].image).astype(np.float32) / np.float32(255.0)
+    ref = a[..., :3] * a[..., 3:] + (1 - a[..., 3:])
+    assert np.abs(N(img) - ref).max() == 0.0
+    assert (N(mask) == (a[..., 3] > 0.3)).all()
+    img3, mask3 = tp.prepare_image(cams[0].image, "cuda")
+    assert (N(img3) == np.asarray(cams[0].image).astype(np.float32) / np.float32(255.0)).all() and N(mask3).all()
+
+
+def test_a24_test_pose_estimation(pkg, e2e):
+    """The loop itself on the reference's rays with the boundary inputs (tokens, camera-up) injected:
+    pose within 1e-4 relative of the reference (north_star tolerance), results schema identical."""
+    g, idm, cams = e2e
+    n = int(g["e2e_n"])
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    toks = [G(g[f"e2e{i}_tokens"]) for i in range(n)]
+    ups = torch.stack([G(g[f"e2e{i}_up"]) for i in range(n)])
+    res, te, ae, ls, rc = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 1.0, 0.0]), "seq", "cat",
+                                                   token_override=toks, up_override=ups, verbose=False, batch_size=3)
+    assert len(res) == n and ls == -1.0 and rc == -1.0
+    assert set(res[0].keys()) == {"sequence_id", "category_name", "frame_id", "loss", "scores_loss", "recall",
+                                  "total_optimization_time_in_ms", "pred_c2w", "gt_c2w"}
+    for i, r in enumerate(res):
+        pred, ref = np.array(r["pred_c2w"], np.float32), g[f"e2e{i}_pred_c2w"]
+        assert np.abs(pred - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), i
+        assert np.abs(np.array(r["gt_c2w"], np.float32) - g[f"e2e{i}_gt_c2w"]).max() < 1e-6
+        assert abs(r["loss"] - float(g[f"e2e{i}_loss"])) < 1e-6
+        assert r["frame_id"] == i and r["sequence_id"] == "seq" and r["category_name"] == "cat"
+    assert abs(te - float(g["e2e_mean_terr"])) < 1e-4 * max(1.0, float(g["e2e_mean_terr"]))
+    assert abs(ae - float(g["e2e_mean_aerr"])) < 1e-2
+
+
+def test_scores_match_reference_through_module(pkg, e2e):
+    g, idm, _ = e2e
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    for i in range(int(g["e2e_n"])):
+        idx, val, sc = idm.score_tokens([G(g[f"e2e{i}_tokens"])], ori, dr, rgb)
+        assert rel_err(N(sc)[0], g[f"e2e{i}_scores"]) < 2e-5
+    # the key cache is reused (same tensors, same weights) ...
+    k1 = idm.ray_keys(ori, dr, rgb)
+    assert idm.ray_keys(ori, dr, rgb) is k1
+    # ... and invalidated when a weight changes in place
+    with torch.no_grad():
+        idm.attention.k_proj.bias.add_(0.0)
+    assert idm.ray_keys(ori, dr, rgb) is not k1
+
+
+def test_full_pipeline_with_backbone_runs(pkg, e2e):
+    """image -> (random-init) ViT-S/14 -> tokens -> scorer -> pose, batched; and test_image's tuple."""
+    g, idm, cams = e2e
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    res, te, ae, _, _ = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 1.0, 0.0]), verbose=False)
+    assert len(res) == 4 and np.isfinite(te) and np.isfinite(ae)
+    tp = importlib.import_module("6dgs_amd.test")
+    img, mask = tp.prepare_image(cams[3].image, "cuda")
+    idx, val, scores, up, amap = idm.test_image(img, mask, ori, dr, rgb, rays_to_output=100)
+    assert idx.shape == (100,) and scores.shape == (ori.shape[0],) and up.shape == (3,)
+    assert amap.shape[-1] == ori.shape[0] and amap.shape[-2] <= 256
+    dense = amap.materialize()
+    assert rel_err(N(dense.sum(0)), N(scores)) < 1e-4
+    assert abs(float(up.norm()) - 1) < 1e-5
