@@ -19,6 +19,14 @@ i32 = C.c_int
 sz = C.c_size_t
 
 
+PROFILE_SLOTS = 128
+
+
+class Profile(C.Structure):
+    _fields_ = [("count", i32), ("start", vp * PROFILE_SLOTS), ("stop", vp * PROFILE_SLOTS),
+                ("flops", C.c_double * PROFILE_SLOTS), ("bytes", C.c_double * PROFILE_SLOTS)]
+
+
 class ScorerWeights(C.Structure):
     _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wk", "bk", "wq", "bq")]
 
@@ -43,6 +51,10 @@ SIGNATURES = {
     "sixdgs_ray_encode": (i32, [vp, vp, vp, i64, vp, vp]),
     "sixdgs_ray_keys_workspace_bytes": (sz, [i64, i64]),
     "sixdgs_ray_keys": (i32, [vp, vp, vp, i64, C.POINTER(ScorerWeights), vp, vp, vp, sz, vp]),
+    "sixdgs_ray_keys_ex": (i32, [vp, vp, vp, i64, C.POINTER(ScorerWeights), vp, vp, vp, sz, vp, C.POINTER(Profile)]),
+    "sixdgs_score_topk_ex": (i32, [vp, vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile)]),
+    "sixdgs_profile_collect": (i32, [C.POINTER(Profile), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(i32)]),
     "sixdgs_linear": (i32, [vp, i64, i32, i64, vp, i64, vp, i32, i32, vp, i64, vp]),
     "sixdgs_q_proj": (i32, [vp, vp, i32, C.POINTER(ScorerWeights), vp, vp]),
     "sixdgs_score_topk_workspace_bytes": (sz, [i64, i32, i32]),

@@ -64,3 +64,22 @@ __device__ __forceinline__ T sdg_block_exclusive_scan(T v, T* smem, T* total) {
   *total = tot;
   return off + inc - v;
 }
+
+// ---- caller-owned kernel timing (include/sixdgs.h: sixdgs_profile) -----------------------------------
+struct SdgProfileScope {
+  sixdgs_profile* p;
+  hipStream_t s;
+  int slot;
+  SdgProfileScope(sixdgs_profile* prof, hipStream_t stream, double flops, double bytes) : p(prof), s(stream), slot(-1) {
+    if (!p || p->count >= SIXDGS_PROFILE_SLOTS) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+    slot = p->count++;
+    p->start[slot] = a; p->stop[slot] = b; p->flops[slot] = flops; p->bytes[slot] = bytes;
+    (void)hipEventRecord(a, s);
+  }
+  ~SdgProfileScope() {
+    if (slot >= 0) (void)hipEventRecord((hipEvent_t)p->stop[slot], s);
+  }
+};

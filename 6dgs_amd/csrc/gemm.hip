@@ -220,6 +220,11 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
                     float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, ws, ws_bytes, stream, nullptr);
+}
+
+int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
+                       float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key));
@@ -232,6 +237,8 @@ int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_
   float* h2 = h1 + chunk * SIXDGS_HID;
   for (int64_t r0 = 0; r0 < r; r0 += chunk) {
     const int64_t m = (r - r0) < chunk ? (r - r0) : chunk;
+    // algorithmic work per ray: ray MLP 1 730 560 + k_proj 294 912 FLOP; 36 B in, 1536 B key out
+    SdgProfileScope scope(prof, s, (double)m * (key ? 2025472.0 : 1730560.0), (double)m * (36.0 + 1536.0));
     int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
     if (st) return st;
     GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};

@@ -395,8 +395,9 @@ size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
   return p.topk_bytes + (size_t)batch * (p.per_image_logits + p.per_image_partial + p.per_image_stats + p.per_image_scores);
 }
 
-int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
-                      int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key, int64_t r,
+                         int topk, float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,
+                         sixdgs_stream_t stream, sixdgs_profile* prof) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && (key || r == 0) && idx && val && ws);
@@ -424,7 +425,12 @@ int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const f
     if (r > 0) {
       LogitsArgs A = {q, d_n_tok, key, logits, partial, r, (int64_t)(p.per_image_logits / sizeof(float) / kT),
                       p.tiles_per_group, p.n_tiles, p.n_groups, b0};
-      hipLaunchKernelGGL(k_logits, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+      {
+        double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
+        for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
+        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * SIXDGS_D * 4.0 + tok * 4.0));
+        hipLaunchKernelGGL(k_logits, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+      }
       hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
       hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
                          d_n_tok, b0, r, sc, sc_stride);
@@ -439,6 +445,32 @@ int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const f
     if (st) return st;
   }
   return 0;
+}
+
+int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
+                      int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream, nullptr);
+}
+
+int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches) {
+  SDG_CHECK_ARG(prof);
+  double ms = 0.0, fl = 0.0, by = 0.0;
+  int n = 0, rc = 0;
+  for (int i = 0; i < prof->count; ++i) {
+    hipEvent_t a = (hipEvent_t)prof->start[i], b = (hipEvent_t)prof->stop[i];
+    float t = 0.f;
+    hipError_t e = hipEventSynchronize(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, a, b);
+    if (e == hipSuccess) { ms += t; fl += prof->flops[i]; by += prof->bytes[i]; ++n; } else rc = (int)e;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+  prof->count = 0;
+  if (ms_total) *ms_total = ms;
+  if (flops_total) *flops_total = fl;
+  if (bytes_total) *bytes_total = by;
+  if (launches) *launches = n;
+  return rc;
 }
 
 }  // extern "C"

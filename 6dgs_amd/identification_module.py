@@ -104,13 +104,13 @@ class IdentificationModule(torch.nn.Module):
             self._key_cache = None
         return self._packed
 
-    def ray_keys(self, rays_ori, rays_dir, rays_rgb) -> torch.Tensor:
+    def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
         """K[R,384] = k_proj(RayPreprocessor(rays)) -- cached per (ray tensors, weights)."""
         w = self.packed_weights(rays_ori.device)
         ident = (rays_ori.data_ptr(), rays_dir.data_ptr(), rays_rgb.data_ptr(), rays_ori.shape[0], rays_ori._version,
                  rays_dir._version, rays_rgb._version, self._packed_key)
         if self._key_cache is None or self._key_cache_id != ident:
-            _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w)
+            _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
             self._key_cache, self._key_cache_id = key, ident
         return self._key_cache
 
@@ -144,14 +144,16 @@ class IdentificationModule(torch.nn.Module):
     # ---- scoring -----------------------------------------------------------------------------------------
     @torch.no_grad()
     def score_tokens(self, token_list: List[torch.Tensor], rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100,
-                     want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
+                     want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
+                     profile=None):
         """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
         key = self.ray_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
         tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
         q = ops.q_proj(tokens, n_tok, w)
         idx, val, scores, _ = ops.score_topk(q, n_tok, key, rays_to_output, want_scores=want_scores, workspace=workspace,
-                                             images_in_flight=images_in_flight)
+                                             images_in_flight=images_in_flight, profile=profile,
+                                             n_tok_host=[int(t.shape[0]) for t in token_list])
         return idx, val, scores
 
     @torch.no_grad()

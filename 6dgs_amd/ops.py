@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ScorerWeights, check
+from ._lib import Profile, ScorerWeights, check
 
 D = 384
 RAY_IN_PAD = 144
@@ -206,6 +206,24 @@ class PackedWeights:
         return C.byref(self.struct)
 
 
+class KernelProfile:
+    """Caller-owned HIP-event timing of the dominant kernel (see sixdgs_profile in include/sixdgs.h)."""
+
+    def __init__(self):
+        self.struct = Profile()
+        self.struct.count = 0
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+    def collect(self):
+        """-> (milliseconds, algorithmic FLOP, algorithmic bytes, launches); waits for the recorded events."""
+        ms, fl, by, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        check(_lib.load().sixdgs_profile_collect(self.ref, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "profile_collect")
+        return ms.value, fl.value, by.value, n.value
+
+
 def ray_encode(ori, dr, rgb) -> torch.Tensor:
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
@@ -225,7 +243,7 @@ def linear(x, w, b=None, relu: bool = False) -> torch.Tensor:
 
 
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
-             workspace: Optional[torch.Tensor] = None):
+             workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None):
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
     lib = _lib.load()
@@ -235,13 +253,13 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     key = torch.empty(r, D, device=dev) if want_key else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.sixdgs_ray_keys(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(ws), ws.numel(), _stream()),
-          "ray_keys")
+    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(ws), ws.numel(), _stream(),
+                                 profile.ref if profile is not None else None), "ray_keys")
     return feat, key
 
 
 def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """list of [T_i, 398] -> tokens [B,256,398] (zero padded), n_tok int32 [B]."""
+    """list of [T_i, 398] -> tokens [B,256,398] (zero padded), n_tok int32 [B] (device)."""
     b = len(token_list)
     tok = torch.zeros(b, MAX_TOKENS, TOK_IN, device=device)
     n = torch.empty(b, dtype=torch.int32)
@@ -267,7 +285,8 @@ def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100) -> int:
 
 
 def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: int = 100, want_scores: bool = True,
-               want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
+               want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
+               profile: Optional["KernelProfile"] = None, n_tok_host=None):
     q, key = _f32(q), _f32(key)
     _need_gpu(q, key, n_tok)
     lib = _lib.load()
@@ -279,8 +298,12 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: in
     if workspace is None:
         inflight = b if images_in_flight is None else max(1, min(b, images_in_flight))
         workspace = torch.empty(score_topk_workspace_bytes(r, inflight, topk), dtype=torch.uint8, device=dev)
-    check(lib.sixdgs_score_topk(_p(q), _p(n_tok), b, _p(key), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
-                                _p(workspace), workspace.numel(), _stream()), "score_topk")
+    h_n = None
+    if profile is not None and n_tok_host is not None:
+        h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
+    check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
+                                   _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None),
+          "score_topk")
     return idx, val, scores, stats
 
 

@@ -50,6 +50,35 @@ def prepare_image(image, device):
     return obs, mask
 
 
+def prepare_image_device(img_u8: torch.Tensor):
+    """Same as prepare_image for a uint8 tensor that already lives on the GPU."""
+    obs = _u8_lut(img_u8.device)[img_u8.long()]
+    if obs.shape[-1] == 4:
+        mask = obs[..., -1] > 0.3
+        obs = torch.multiply(obs[..., :3], obs[..., -1:]) + (1 - obs[..., -1:])
+    else:
+        mask = torch.ones_like(obs[..., -1], dtype=torch.bool)
+    return obs, mask
+
+
+@torch.no_grad()
+def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
+                   images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False):
+    """One batch of the hot path: query images (uint8 [H,W,3|4] tensors on the GPU) -> poses.
+    image prep -> backbone tokens + camera-up (PyTorch-ROCm) -> q_proj / scorer / top-k / pose solve (HIP).
+    `tokens` / `up` inject the image-side boundary inputs instead.  Everything is enqueued on the current
+    stream; nothing syncs until the caller reads the returned device tensors."""
+    if tokens is None:
+        prepared = [prepare_image_device(im) for im in images]
+        tokens, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] for p in prepared])
+        up = id_module.camera_up(fmaps)
+    idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
+                                                  workspace=workspace, images_in_flight=images_in_flight, profile=profile)
+    sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt_c2w)
+    sol.update(idx=idx, weights=weights, scores=scores, tokens=tokens, up=up)
+    return sol
+
+
 def gt_pose_and_intrinsics(camera_info, device):
     """test.py:47-67 (on the host: 4x4 inverse of [R^T | T])."""
     w2c = torch.eye(4, dtype=torch.float32)

@@ -44,6 +44,20 @@ extern "C" {
 
 typedef void* sixdgs_stream_t;
 
+/* Optional kernel timing, owned by the caller (the library stays stateless): zero-initialise, pass to
+ * the *_ex entry points; each launch of the dominant kernel is bracketed by a pair of HIP events on
+ * the launch stream and its algorithmic FLOP count recorded.  sixdgs_profile_collect waits for the
+ * events, sums milliseconds and FLOPs, destroys the events and resets the struct. */
+#define SIXDGS_PROFILE_SLOTS 128
+typedef struct sixdgs_profile {
+  int count;
+  void* start[SIXDGS_PROFILE_SLOTS];
+  void* stop[SIXDGS_PROFILE_SLOTS];
+  double flops[SIXDGS_PROFILE_SLOTS];
+  double bytes[SIXDGS_PROFILE_SLOTS];
+} sixdgs_profile;
+int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches);
+
 int sixdgs_abi_version(void);
 const char* sixdgs_error_string(int status);
 
@@ -149,6 +163,9 @@ int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int6
 size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk);
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
                     float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+/* same, timing the whole MLP chain of each chunk (2 025 472 algorithmic FLOP per ray) into `prof` */
+int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
+                       float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
 
 /* generic fp32 MFMA GEMM used by the above: y[M,N] = act(x[M,K] . w[N,K]^T + b), K % 16 == 0,
  * N % 128 == 0, ldx/ldw/ldy in floats and multiples of 4. */
@@ -174,6 +191,10 @@ int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, in
                       int64_t r, int topk, float* scores /*[B,R] or NULL*/, int64_t* idx /*[B,topk]*/,
                       float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,
                       size_t ws_bytes, sixdgs_stream_t stream);
+/* same, timing each launch of the logits kernel (2*T*384 algorithmic FLOP per ray and image) into `prof` */
+int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy, for the FLOP count*/,
+                         int batch, const float* key, int64_t r, int topk, float* scores, int64_t* idx, float* val,
+                         float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,
