@@ -1,0 +1,121 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/sixdgs.h declares (no compute
+calls without a GPU), the product path refuses to run without the GPU, and the host-side logic
+(token padding, image prep, sharding, results schema helpers) behaves."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "sixdgs.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sixdgs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    b = importlib.import_module("6dgs_amd.build")
+    lib = C.CDLL(b.build())
+    syms = header_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/sixdgs.h but not exported"
+    L = importlib.import_module("6dgs_amd._lib")
+    assert set(L.SIGNATURES) == set(syms), set(L.SIGNATURES) ^ set(syms)
+    assert L.load().sixdgs_abi_version() == 1
+    # argument errors are reported without touching the GPU
+    assert L.load().sixdgs_mask_degraded(None, -1, 50, None, None) == -1
+    assert b"bad argument" in L.load().sixdgs_error_string(-1)
+    assert L.load().sixdgs_packed_weights_floats() > 1_000_000
+    assert L.load().sixdgs_score_topk_workspace_bytes(32_000_000, 1, 100) > 32_000_000 * 1024
+
+
+def test_product_path_has_no_cpu_fallback(syn):
+    pkg = importlib.import_module("6dgs_amd")
+    ops = importlib.import_module("6dgs_amd.ops")
+    scene = pkg.GaussianScene.from_dict(syn.make_scene(10, 0), device="cpu")
+    with pytest.raises(RuntimeError):
+        pkg.generate_all_possible_rays(scene)
+    with pytest.raises(RuntimeError):
+        ops.mask_degraded(torch.zeros(4, 3))
+    with pytest.raises(RuntimeError):
+        pkg.test_pose_estimation([], None.__class__ and pkg.IdentificationModule("dino"), torch.zeros(4, 3), torch.zeros(4, 3),
+                                 torch.zeros(4, 3), torch.tensor([0.0, 1.0, 0.0]), verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "6dgs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", "").replace("like the oracle", "") \
+                    or f in ("hostcheck.cpp", "device_math.h", "pose.hip", "__init__.py"), f
+                assert "import oracle" not in txt and "from oracle" not in txt and "sixdgs_oracle" not in txt, f
+
+
+def test_state_dict_keys_match_reference(syn):
+    pkg = importlib.import_module("6dgs_amd")
+    idm = pkg.IdentificationModule("dino")
+    sd = syn.make_scorer_state_dict(0, with_cnn=True)
+    res = idm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.startswith("backbone_wrapper.image_preprocessing_net") for k in res.missing_keys)
+    assert idm.state_dict()["ray_preprocessor.mlp2.0.weight"].shape == (512, 653)
+    assert idm.state_dict()["attention.q_proj.weight"].shape == (384, 398)
+    with pytest.raises(NotImplementedError):
+        idm(None)
+
+
+def test_image_prep_and_gt_pose_on_cpu(syn):
+    tp = importlib.import_module("6dgs_amd.test")
+    pkg = importlib.import_module("6dgs_amd")
+    cam = pkg.CameraInfo(**syn.make_cameras(1, 1, 32, 24, rgba=True)[0])
+    img, mask = tp.prepare_image(cam.image, "cpu")
+    a = np.asarray(cam.image).astype(np.float32) / np.float32(255)
+    assert np.abs(img.numpy() - (a[..., :3] * a[..., 3:] + (1 - a[..., 3:]))).max() == 0
+    assert (mask.numpy() == (a[..., 3] > 0.3)).all()
+    c2w, K = tp.gt_pose_and_intrinsics(cam, "cpu")
+    w2c = np.eye(4)
+    w2c[:3, :3] = cam.R.T
+    w2c[:3, 3] = cam.T
+    assert np.abs(c2w.numpy() - np.linalg.inv(w2c)).max() < 1e-5
+    assert abs(K[0, 0].item() - 32 / (2 * np.tan(0.4))) < 1e-3 and K[0, 2].item() == 16
+
+
+def test_backbone_wrapper_shapes_cpu():
+    bb = importlib.import_module("6dgs_amd.backbone")
+    w = bb.BackboneWrapper("dino", backbone=bb.ViTS14(depth=1))
+    img = torch.rand(60, 80, 3)
+    mask = torch.zeros(60, 80, dtype=torch.bool)
+    mask[:, 20:60] = True
+    with torch.no_grad():
+        t_pe, t, fmap = w(img, mask)
+    assert t_pe.shape[1] == 398 and t.shape[1] == 384 and fmap.shape == (384, 16, 16)
+    assert 0 < t_pe.shape[0] < 256 and t_pe.shape[0] == t.shape[0]
+    pe = w.get_img_position_encoding((16, 16), 3)
+    assert pe.shape == (16, 16, 14) and pe[0, 0, 0] == -1 and pe[15, 15, 1] == 1
+
+
+def test_pad_tokens_cpu():
+    ops = importlib.import_module("6dgs_amd.ops")
+    tok, n = ops.pad_tokens([torch.ones(3, 398), torch.ones(0, 398), torch.ones(256, 398)], "cpu")
+    assert tok.shape == (3, 256, 398) and n.tolist() == [3, 0, 256] and tok[0, 3:].abs().sum() == 0
+    with pytest.raises(RuntimeError):
+        ops.pad_tokens([torch.ones(257, 398)], "cpu")
+
+
+def test_shard_range_covers_everything():
+    dd = importlib.import_module("6dgs_amd.distributed")
+    for n in (0, 1, 7, 64, 128, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [dd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

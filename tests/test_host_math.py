@@ -1,0 +1,130 @@
+"""CPU tests of the PRODUCT's per-thread math: 6dgs_amd/csrc/device_math.h compiled for the host
+(libsixdgs_hostcheck.so) against the oracle and the reference-generated goldens.  This is the same
+source the HIP kernels instantiate on the device, so arithmetic bugs surface here without a GPU."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import quadricell_tie_cells
+
+
+@pytest.fixture(scope="module")
+def hc():
+    b = importlib.import_module("6dgs_amd.build")
+    lib = C.CDLL(b.build_hostcheck())
+    lib.hc_quadricell_centers.restype = C.c_longlong
+    lib.hc_emit_rays.restype = C.c_longlong
+    lib.hc_isocell_dirs.restype = C.c_longlong
+    return lib
+
+
+def P(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def test_mask_degraded(hc, golden):
+    g = golden("g1_quadricell")
+    sc = f32(g["a2_scale"])
+    m = np.zeros(sc.shape[0], np.uint8)
+    hc.hc_mask_degraded(P(sc), C.c_longlong(sc.shape[0]), 50, P(m, C.c_ubyte))
+    assert (m.astype(bool) == g["a2_mask"]).all()
+
+
+@pytest.mark.parametrize("Pt", [50, 64, 256])
+def test_quadricell_and_emission(hc, golden, Pt):
+    g = golden("g1_quadricell")
+    sc = f32(g["scale"])
+    E = sc.shape[0]
+    n = hc.hc_quadricell_centers(P(sc), C.c_longlong(E), Pt, 1000, None, None)
+    ref = g[f"P{Pt}_points"]
+    assert n == ref.shape[0]
+    pts = np.zeros((n, 3), np.float32)
+    eid = np.zeros(n, np.int64)
+    hc.hc_quadricell_centers(P(sc), C.c_longlong(E), Pt, 1000, P(pts), P(eid, C.c_longlong))
+    assert (eid == g[f"P{Pt}_eid"]).all()
+    d = np.abs(pts - ref).max(1)
+    ties = quadricell_tie_cells(eid, ref)
+    assert (d[~ties] < 1e-6).all()
+    # emission on the REFERENCE's cell centres: identical ray set
+    ori = np.zeros((n, 3), np.float32)
+    dr = np.zeros((n, 3), np.float32)
+    mid = np.zeros(n, np.int64)
+    r = hc.hc_emit_rays(P(f32(ref)), P(np.ascontiguousarray(g[f"P{Pt}_eid"]), C.c_longlong), C.c_longlong(n), P(f32(g["normals"])),
+                        P(f32(g["xyz"])), P(f32(g["rot"])), P(ori), P(dr), P(mid, C.c_longlong))
+    assert r == g[f"P{Pt}_ori"].shape[0]
+    assert (mid[:r] == g[f"P{Pt}_mid"]).all()
+    assert np.abs(ori[:r] - g[f"P{Pt}_ori"]).max() < 1e-6 and np.abs(dr[:r] - g[f"P{Pt}_dir"]).max() < 1e-6
+
+
+def test_sym_eig_and_normals(hc, oracle, golden):
+    g = golden("g2_normals")
+    mats = f32(g["mats"])
+    vals = np.zeros((mats.shape[0], 3), np.float32)
+    vecs = np.zeros((mats.shape[0], 3, 3), np.float32)
+    hc.hc_sym_eig(P(mats), C.c_longlong(mats.shape[0]), P(vals), P(vecs))
+    ov, oe = oracle.sym_eig_3x3(mats)
+    scale = np.abs(ov[:200]).max(1, keepdims=True)
+    assert (np.abs(vals[:200] - ov[:200]) / scale).max() < 2e-5
+    gap = np.minimum(ov[:200, 1] - ov[:200, 0], ov[:200, 2] - ov[:200, 1]) / scale[:, 0]
+    assert np.abs(vecs[:200][gap > 1e-2] - oe[:200][gap > 1e-2]).max() < 2e-3
+    # normals from the reference's own neighbour lists
+    pts = f32(g["pts"])
+    knn = np.ascontiguousarray(g["knn"], np.int64)
+    n = np.zeros((pts.shape[0], 3), np.float32)
+    hc.hc_normals_from_knn(P(pts), P(knn, C.c_longlong), C.c_longlong(pts.shape[0]), 20, P(n))
+    assert np.abs(n - g["normals"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("tgt,n0", [(35, 3), (64, 1), (256, 1)])
+def test_isocell(hc, golden, tgt, n0):
+    g = golden("g3_isocell")
+    ref = g[f"dirs_{tgt}_{n0}"]
+    d = np.zeros_like(ref)
+    assert hc.hc_isocell_dirs(tgt, n0, P(d)) == ref.shape[0]
+    assert np.abs(d - ref).max() < 5e-7
+    if n0 == 1:
+        out = np.zeros((g["normals"].shape[0], ref.shape[0], 3), np.float32)
+        hc.hc_rotate_isocell(P(f32(ref)), C.c_longlong(ref.shape[0]), P(f32(g["normals"])), C.c_longlong(g["normals"].shape[0]), P(out))
+        r = g[f"rot_{tgt}"]
+        assert (np.isnan(out) == np.isnan(r)).all() and np.nanmax(np.abs(out - r)) < 1e-6
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colour(hc, golden, deg):
+    g = golden("g4_sh")
+    out = np.zeros((g["dir"].shape[0], 3), np.float32)
+    hc.hc_sh_color(P(f32(g["sh"])), 16, P(f32(g["dir"])), C.c_longlong(g["dir"].shape[0]), deg, P(out))
+    assert np.abs(out - g[f"rgb_deg{deg}"]).max() < 1e-6
+
+
+def test_ray_input(hc, oracle, syn):
+    r = syn.make_rays(256, 0)
+    x = np.zeros((256, 144), np.float32)
+    hc.hc_ray_input(P(r["ori"]), P(r["dir"]), P(r["rgb"]), C.c_longlong(256), P(x))
+    assert np.abs(x[:, :141] - oracle.ray_input(r["ori"], r["dir"], r["rgb"])).max() < 2e-7
+    assert (x[:, 141:] == 0).all()
+
+
+def test_rotation_centre_errors(hc, oracle, golden):
+    g = golden("g6_pose")
+    for d, u, ref in list(zip(g["rot_dirs"], g["rot_ups"], g["rot_mats"]))[2:]:
+        m = np.zeros((3, 3), np.float32)
+        hc.hc_make_rotation_mat(P(f32(d)), P(f32(u)), P(m))
+        assert np.abs(m - ref).max() < 1e-6
+    # exactly singular normal matrix -> NaN centre (line_intersection.py:139-142)
+    Rm = f32(np.diag([100.0, 100.0, 0.0]))
+    c = np.zeros(3, np.float32)
+    assert hc.hc_solve_centre(P(Rm), P(f32([1, 2, 3])), P(c)) == 0 and np.isnan(c).all()
+    Rm = f32([[4, 1, 0], [1, 3, 1], [0, 1, 2]])
+    assert hc.hc_solve_centre(P(Rm), P(f32([1, 2, 3])), P(c)) == 1
+    assert np.abs(c - np.linalg.solve(Rm.astype(np.float64), [1, 2, 3])).max() < 1e-6
+    gt, pr = f32(g["plain_gt"]), f32(g["plain_c2w"])
+    e = np.zeros(2, np.float32)
+    hc.hc_pose_errors(P(gt), P(pr), P(e))
+    assert abs(e[0] - float(g["plain_terr"])) < 1e-5 and abs(e[1] - float(g["plain_aerr"])) < 1e-3
