@@ -11,15 +11,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // y[M,N] = act(A . W^T + b)
 // ------------------------------------------------------------------------------------------------
-template <int WM, bool RELU>
-__global__ void __launch_bounds__(WM * 128, 2) k_linear(GemmOperands g, const float* __restrict__ bias, float* __restrict__ y,
-                                                         int64_t ldy, unsigned n_tiles, unsigned total_tiles) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * GemmSmem<WM>::kStageFloats];
+template <int MMA, bool RELU>
+__global__ void __launch_bounds__(256, 2) k_linear(GemmOperands g, const float* __restrict__ bias, float* __restrict__ y,
+                                                    int64_t ldy, unsigned n_tiles, unsigned total_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[TileSmem<MMA>::kBytes];
   const unsigned w = xcd_remap(blockIdx.x, total_tiles);
-  const int64_t row0 = (int64_t)(w / n_tiles) * (WM * 64);
+  const int64_t row0 = (int64_t)(w / n_tiles) * 128;
   const int64_t col0 = (int64_t)(w % n_tiles) * kBN;
   f32x16 acc[2][2];
-  gemm_mainloop<WM>(g, row0, col0, smem, acc);
+  gemm_tile<MMA>(g, row0, col0, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -40,18 +40,25 @@ __global__ void __launch_bounds__(WM * 128, 2) k_linear(GemmOperands g, const fl
   }
 }
 
-template <int WM>
-int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, hipStream_t s) {
-  const int64_t m_tiles = sdg_cdiv(g.m, WM * 64), n_tiles = sdg_cdiv(g.n, kBN);
+int resolve_mma(int mode) {
+  if (mode == SIXDGS_MMA_F32 || mode == SIXDGS_MMA_BF16X6) return mode;
+  return SIXDGS_MMA_BF16X6;  // SIXDGS_MMA_DEFAULT
+}
+
+int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, hipStream_t s, int mma) {
+  const int64_t m_tiles = sdg_cdiv(g.m, 128), n_tiles = sdg_cdiv(g.n, kBN);
   const int64_t total = m_tiles * n_tiles;
   if (total <= 0) return 0;
   if (total > 0x7fffffffLL) return SIXDGS_E_BADARG;
-  if (relu)
-    hipLaunchKernelGGL((k_linear<WM, true>), dim3((unsigned)total), dim3(WM * 128), 0, s, g, bias, y, ldy, (unsigned)n_tiles,
-                       (unsigned)total);
-  else
-    hipLaunchKernelGGL((k_linear<WM, false>), dim3((unsigned)total), dim3(WM * 128), 0, s, g, bias, y, ldy, (unsigned)n_tiles,
-                       (unsigned)total);
+  const dim3 grid((unsigned)total), blk(256);
+  const unsigned nt = (unsigned)n_tiles, tt = (unsigned)total;
+  if (resolve_mma(mma) == SIXDGS_MMA_BF16X6) {
+    if (relu) hipLaunchKernelGGL((k_linear<kMmaBf16x6, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+    else hipLaunchKernelGGL((k_linear<kMmaBf16x6, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+  } else {
+    if (relu) hipLaunchKernelGGL((k_linear<kMmaF32, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+    else hipLaunchKernelGGL((k_linear<kMmaF32, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+  }
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -203,12 +210,17 @@ int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int6
 
 int sixdgs_linear(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n, int relu,
                   float* y, int64_t ldy, sixdgs_stream_t stream) {
+  return sixdgs_linear_ex(x, m, k, ldx, w, ldw, b, n, relu, y, ldy, stream, SIXDGS_MMA_DEFAULT);
+}
+
+int sixdgs_linear_ex(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n, int relu,
+                     float* y, int64_t ldy, sixdgs_stream_t stream, int mma_mode) {
   SDG_CHECK_ARG(m >= 0 && n > 0 && k > 0 && (k % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0 && ldx >= k && ldw >= k && ldy >= n);
   if (m == 0) return 0;
   SDG_CHECK_ARG(x && w && y);
   SDG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0);
   GemmOperands g = {x, nullptr, w, ldx, 0, ldw, m, n, k, k};
-  return launch_linear<2>(g, b, relu != 0, y, ldy, sdg_stream(stream));
+  return launch_linear(g, b, relu != 0, y, ldy, sdg_stream(stream), mma_mode);
 }
 
 size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
@@ -220,11 +232,11 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
                     float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, ws, ws_bytes, stream, nullptr);
+  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
-                       float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
+                       float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key));
@@ -242,19 +254,19 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
     int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
     if (st) return st;
     GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
-    if ((st = launch_linear<2>(g1, w->b1, true, h1, SIXDGS_HID, s))) return st;
+    if ((st = launch_linear(g1, w->b1, true, h1, SIXDGS_HID, s, mma_mode))) return st;
     GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID};
-    if ((st = launch_linear<2>(g2, w->b2, true, h2, SIXDGS_HID, s))) return st;
+    if ((st = launch_linear(g2, w->b2, true, h2, SIXDGS_HID, s, mma_mode))) return st;
     // layer 3 consumes the concatenation [h2, x] without materialising it (two A segments)
     GemmOperands g3 = {h2, x, w->w3, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_HID + SIXDGS_RAY_IN_PAD, m, SIXDGS_HID,
                        SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID};
-    if ((st = launch_linear<2>(g3, w->b3, true, h1, SIXDGS_HID, s))) return st;
+    if ((st = launch_linear(g3, w->b3, true, h1, SIXDGS_HID, s, mma_mode))) return st;
     float* f = feat ? feat + r0 * SIXDGS_D : h2;
     GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID};
-    if ((st = launch_linear<2>(g4, w->b4, false, f, SIXDGS_D, s))) return st;
+    if ((st = launch_linear(g4, w->b4, false, f, SIXDGS_D, s, mma_mode))) return st;
     if (key) {
       GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
-      if ((st = launch_linear<2>(g5, w->bk, false, key + r0 * SIXDGS_D, SIXDGS_D, s))) return st;
+      if ((st = launch_linear(g5, w->bk, false, key + r0 * SIXDGS_D, SIXDGS_D, s, mma_mode))) return st;
     }
   }
   return 0;

@@ -47,6 +47,20 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + slot;
 }
 
+// Guarded 16-byte operand load without a branch: the address is clamped into the matrix (row -> last valid
+// row, k -> 0) so the load is always legal, and the value is zeroed by a select.  A conditional load would be
+// scalarised by hipcc into four exec-masked global_load_dword (measured: 3x slower kernel).
+__device__ __forceinline__ float4 load4_guarded(const float* base, int64_t row, int64_t rows, int64_t ld, int k, bool k_ok) {
+  const bool ok = k_ok && row < rows;
+  const int64_t rc = row < rows ? row : rows - 1;
+  float4 v = *reinterpret_cast<const float4*>(base + rc * ld + (k_ok ? k : 0));
+  v.x = ok ? v.x : 0.f;
+  v.y = ok ? v.y : 0.f;
+  v.z = ok ? v.z : 0.f;
+  v.w = ok ? v.w : 0.f;
+  return v;
+}
+
 template <int WM>
 struct GemmSmem {
   static constexpr int BM = WM * 64;
@@ -88,15 +102,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& g, int64_t row
     const int64_t lda = seg1 ? g.lda1 : g.lda0;
     const int ka = seg1 ? kk - g.k0 : kk;
 #pragma unroll
-    for (int p = 0; p < APASS; ++p) {
-      const int64_t r = row0 + p * (NT / 8) + lrow;
-      ra[p] = (kin && r < g.m) ? *reinterpret_cast<const float4*>(abase + r * lda + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int p = 0; p < APASS; ++p) ra[p] = load4_guarded(abase, row0 + p * (NT / 8) + lrow, g.m, lda, ka, kin);
 #pragma unroll
-    for (int p = 0; p < BPASS; ++p) {
-      const int64_t r = col0 + p * (NT / 8) + lrow;
-      rb[p] = (kin && r < g.n) ? *reinterpret_cast<const float4*>(g.b + r * g.ldb + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int p = 0; p < BPASS; ++p) rb[p] = load4_guarded(g.b, col0 + p * (NT / 8) + lrow, g.n, g.ldb, kk, kin);
   };
   auto store_slab = [&](int buf) {
     float* sa = smem + buf * kStage;
@@ -147,6 +155,130 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& g, int64_t row
     if (s + 1 < nslab) store_slab(buf ^ 1);
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16x6 variant: the same fp32 product on the bf16 matrix pipe (16x the fp32 MFMA rate).
+// Every fp32 operand value is split on the fly into three bf16 planes x = h + m + l (round-to-nearest,
+// exact: 3 x 8 significant bits cover the 24-bit mantissa) and the six leading cross terms
+//   l*h + h*l + m*m + m*h + h*m + h*h       (dropped: m*l, l*m, l*l <= 2^-26 |x||y|)
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Each bf16 x bf16 product is
+// exact in fp32, so the only rounding is the accumulation: measured error 1.3e-7 * sum|a||b| at K = 384
+// versus 1.6e-7 for the fp32 MFMA chain (tools/probe_bf16x6.*).  6 MFMAs of 32 cycles per
+// 32x32x16 block against 8 x 64 cycles for v_mfma_f32_32x32x2_f32: 2.67x less matrix-pipe time.
+//
+// LDS image of a slab (32 k): per row 3 planes x 32 bf16 = 3 x 64 B, row stride 208 B (13 x 16 B: odd
+// multiple of the 16-byte slot, so the 16-lane groups of ds_read_b128 hit 16 distinct slots).  Operand
+// layout of v_mfma_f32_32x32x16_bf16: lane l holds row l&31, k = 8*(l>>5) .. +7 -> one 16-byte read per
+// (row block, plane, k-step).  Single LDS buffer (53 KB -> up to 3 workgroups per CU) with the next slab's
+// global loads held in registers during the MFMAs; two barriers per slab.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+constexpr int kB6Row = 208;
+constexpr int kB6Bytes = (128 + kBN) * kB6Row;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// two fp32 values -> one packed dword per plane
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = pack_bf16(ra, rb);
+  l = pack_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ void split_store8(const float4& lo, const float4& hi, char* dst) {
+  uint4 h, m, l;
+  split_pair(lo.x, lo.y, h.x, m.x, l.x);
+  split_pair(lo.z, lo.w, h.y, m.y, l.y);
+  split_pair(hi.x, hi.y, h.z, m.z, l.z);
+  split_pair(hi.z, hi.w, h.w, m.w, l.w);
+  *reinterpret_cast<uint4*>(dst) = h;
+  *reinterpret_cast<uint4*>(dst + 64) = m;
+  *reinterpret_cast<uint4*>(dst + 128) = l;
+}
+
+__device__ __forceinline__ void gemm_mainloop_b6(const GemmOperands& g, int64_t row0, int64_t col0, char* smem,
+                                                 f32x16 (&acc)[2][2]) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 2, lchunk = tid & 3;   // loader: 4 lanes x 32 B cover one 128-B row segment
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2][2], rb[2][2];
+  const int nslab = (g.k + kBK - 1) / kBK;
+  auto load_slab = [&](int s) {
+    const int kk = s * kBK + lchunk * 8;
+    const bool seg1 = g.a1 != nullptr && kk >= g.k0;
+    const float* abase = seg1 ? g.a1 : g.a0;
+    const int64_t lda = seg1 ? g.lda1 : g.lda0;
+    const int ka = seg1 ? kk - g.k0 : kk;
+    const bool k0ok = kk < g.k, k1ok = kk + 4 < g.k;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      ra[p][0] = load4_guarded(abase, row0 + p * 64 + lrow, g.m, lda, ka, k0ok);
+      ra[p][1] = load4_guarded(abase, row0 + p * 64 + lrow, g.m, lda, ka + 4, k1ok);
+      rb[p][0] = load4_guarded(g.b, col0 + p * 64 + lrow, g.n, g.ldb, kk, k0ok);
+      rb[p][1] = load4_guarded(g.b, col0 + p * 64 + lrow, g.n, g.ldb, kk + 4, k1ok);
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      split_store8(ra[p][0], ra[p][1], smem + (p * 64 + lrow) * kB6Row + lchunk * 16);
+      split_store8(rb[p][0], rb[p][1], smem + (128 + p * 64 + lrow) * kB6Row + lchunk * 16);
+    }
+  };
+
+  load_slab(0);
+  const char* sa = smem + (wm * 64 + (lane & 31)) * kB6Row + (lane >> 5) * 16;
+  const char* sb = smem + (128 + wn * 64 + (lane & 31)) * kB6Row + (lane >> 5) * 16;
+  for (int s = 0; s < nslab; ++s) {
+    store_slab();
+    __syncthreads();
+    if (s + 1 < nslab) load_slab(s + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[t][p] = *reinterpret_cast<const bf16x8*>(sa + t * 32 * kB6Row + p * 64 + ks * 32);
+          b[t][p] = *reinterpret_cast<const bf16x8*>(sb + t * 32 * kB6Row + p * 64 + ks * 32);
+        }
+      // (A plane, B plane) pairs, smallest magnitude first; 4 independent accumulators per pair
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], b[0][PB[q]], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], b[1][PB[q]], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], b[0][PB[q]], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], b[1][PB[q]], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kMmaF32 = 0, kMmaBf16x6 = 1;
+template <int MMA>
+struct TileSmem {
+  static constexpr int kBytes = MMA == kMmaBf16x6 ? kB6Bytes : GemmSmem<2>::kBytes;
+};
+template <int MMA>
+__device__ __forceinline__ void gemm_tile(const GemmOperands& g, int64_t row0, int64_t col0, char* smem, f32x16 (&acc)[2][2]) {
+  if constexpr (MMA == kMmaBf16x6) gemm_mainloop_b6(g, row0, col0, smem, acc);
+  else gemm_mainloop<2>(g, row0, col0, reinterpret_cast<float*>(smem), acc);
 }
 
 // row / column (relative to the workgroup tile) of accumulator element (tm, tn, r) of this lane

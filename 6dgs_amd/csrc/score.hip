@@ -33,8 +33,9 @@ struct LogitsArgs {
   int b0;                // first image of this group in q / n_tok
 };
 
+template <int MMA>
 __global__ void __launch_bounds__(256, 2) k_logits(LogitsArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * GemmSmem<2>::kStageFloats];
+  __shared__ __attribute__((aligned(16))) char smem[TileSmem<MMA>::kBytes];
   __shared__ float part[2][128][2];
   const int bl = blockIdx.y;            // image within the group
   const int b = A.b0 + bl;
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256, 2) k_logits(LogitsArgs A) {
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int64_t col0 = (int64_t)tile * kBN;
       f32x16 acc[2][2];
-      gemm_mainloop<2>(g, row0, col0, smem, acc);
+      gemm_tile<MMA>(g, row0, col0, smem, acc);
       const int64_t c0 = col0 + acc_col(wn, 0, lane), c1 = col0 + acc_col(wn, 1, lane);
       const bool v0 = c0 < A.r, v1 = c1 < A.r;
 #pragma unroll
@@ -397,7 +398,7 @@ size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
 
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key, int64_t r,
                          int topk, float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,
-                         sixdgs_stream_t stream, sixdgs_profile* prof) {
+                         sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && (key || r == 0) && idx && val && ws);
@@ -429,7 +430,10 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
         SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * SIXDGS_D * 4.0 + tok * 4.0));
-        hipLaunchKernelGGL(k_logits, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+        if (mma_mode == SIXDGS_MMA_F32)
+          hipLaunchKernelGGL(k_logits<kMmaF32>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+        else
+          hipLaunchKernelGGL(k_logits<kMmaBf16x6>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
       }
       hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
       hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
@@ -449,7 +453,8 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
 
 int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
                       int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream, nullptr);
+  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream, nullptr,
+                              SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches) {

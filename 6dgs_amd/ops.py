@@ -12,6 +12,20 @@ from . import _lib
 from ._lib import Profile, ScorerWeights, check
 
 D = 384
+MMA_DEFAULT, MMA_F32, MMA_BF16X6 = -1, 0, 1
+_mma_mode = MMA_DEFAULT
+
+
+def set_mma_mode(mode: int):
+    """Select how the fp32 contractions run on the matrix cores (see SIXDGS_MMA_* in include/sixdgs.h)."""
+    global _mma_mode
+    assert mode in (MMA_DEFAULT, MMA_F32, MMA_BF16X6)
+    _mma_mode = mode
+
+
+def get_mma_mode() -> int:
+    return _mma_mode
+
 RAY_IN_PAD = 144
 TOK_IN = 398
 MAX_TOKENS = 256
@@ -232,13 +246,13 @@ def ray_encode(ori, dr, rgb) -> torch.Tensor:
     return x
 
 
-def linear(x, w, b=None, relu: bool = False) -> torch.Tensor:
+def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None) -> torch.Tensor:
     x, w = _f32(x), _f32(w)
     _need_gpu(x, w)
     b = _f32(b) if b is not None else None
     y = torch.empty(x.shape[0], w.shape[0], device=x.device)
-    check(_lib.load().sixdgs_linear(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(w), w.stride(0), _p(b), w.shape[0], int(relu),
-                                    _p(y), y.stride(0), _stream()), "linear")
+    check(_lib.load().sixdgs_linear_ex(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(w), w.stride(0), _p(b), w.shape[0], int(relu),
+                                       _p(y), y.stride(0), _stream(), _mma_mode if mma_mode is None else mma_mode), "linear")
     return y
 
 
@@ -254,7 +268,7 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(ws), ws.numel(), _stream(),
-                                 profile.ref if profile is not None else None), "ray_keys")
+                                 profile.ref if profile is not None else None, _mma_mode), "ray_keys")
     return feat, key
 
 
@@ -302,8 +316,8 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: in
     if profile is not None and n_tok_host is not None:
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
     check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
-                                   _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None),
-          "score_topk")
+                                   _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,
+                                   _mma_mode), "score_topk")
     return idx, val, scores, stats
 
 

@@ -44,6 +44,15 @@ extern "C" {
 
 typedef void* sixdgs_stream_t;
 
+/* How the fp32 contractions are evaluated on the matrix cores (results agree to fp32 rounding):
+ *   F32     v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s peak;
+ *   BF16X6  each fp32 operand split into 3 bf16 planes, the 6 leading cross terms accumulated in fp32 by
+ *           v_mfma_f32_32x32x16_bf16: per-product error <= 2^-26 (below fp32 rounding), 2.67x less
+ *           matrix-pipe time.  DEFAULT = BF16X6. */
+#define SIXDGS_MMA_DEFAULT (-1)
+#define SIXDGS_MMA_F32 0
+#define SIXDGS_MMA_BF16X6 1
+
 /* Optional kernel timing, owned by the caller (the library stays stateless): zero-initialise, pass to
  * the *_ex entry points; each launch of the dominant kernel is bracketed by a pair of HIP events on
  * the launch stream and its algorithmic FLOP count recorded.  sixdgs_profile_collect waits for the
@@ -165,12 +174,15 @@ int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_
                     float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing the whole MLP chain of each chunk (2 025 472 algorithmic FLOP per ray) into `prof` */
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
-                       float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
+                       float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
+                       int mma_mode);
 
 /* generic fp32 MFMA GEMM used by the above: y[M,N] = act(x[M,K] . w[N,K]^T + b), K % 16 == 0,
  * N % 128 == 0, ldx/ldw/ldy in floats and multiples of 4. */
 int sixdgs_linear(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
                   int relu, float* y, int64_t ldy, sixdgs_stream_t stream);
+int sixdgs_linear_ex(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
+                     int relu, float* y, int64_t ldy, sixdgs_stream_t stream, int mma_mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Scorer, image side (per batch of query images)
@@ -194,7 +206,8 @@ int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, in
 /* same, timing each launch of the logits kernel (2*T*384 algorithmic FLOP per ray and image) into `prof` */
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy, for the FLOP count*/,
                          int batch, const float* key, int64_t r, int topk, float* scores, int64_t* idx, float* val,
-                         float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
+                         float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
+                         int mma_mode);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

@@ -195,8 +195,11 @@ def test_a10_sh_colour(ops, golden, deg):
 # ------------------------------------------------------------------------------------------------
 # scorer
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def scorer(ops, oracle, golden, syn):
+@pytest.fixture(scope="module", params=["bf16x6", "f32"])
+def scorer(request, ops, oracle, golden, syn):
+    """Runs every scorer test under both matrix-core modes (SIXDGS_MMA_BF16X6 is the default)."""
+    ops.set_mma_mode(ops.MMA_BF16X6 if request.param == "bf16x6" else ops.MMA_F32)
+    request.addfinalizer(lambda: ops.set_mma_mode(ops.MMA_DEFAULT))
     g = golden("g5_scorer")
     sd = syn.make_scorer_state_dict(0)
     rays = syn.make_rays(4096, 0)
@@ -215,19 +218,31 @@ def test_a12_ray_encode(ops, oracle, scorer):
     assert (x[:, 141:] == 0).all()
 
 
-def test_linear_mfma_vs_fp64(ops):
-    """The fp32 MFMA tile kernel against an fp64 product, with an asymmetric weight matrix (catches
-    transposed fragments) and ragged M / K tails."""
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_linear_mfma_vs_fp64(ops, mode):
+    """Both tile kernels (fp32 MFMA chain; 3-plane bf16 split with 6 cross terms) against an fp64 product,
+    with an asymmetric weight matrix (catches transposed fragments) and ragged M / K tails."""
+    mm = ops.MMA_BF16X6 if mode == "bf16x6" else ops.MMA_F32
     rng = np.random.default_rng(0)
-    for m, k, n in ((300, 144, 512), (128, 656, 512), (1000, 384, 384), (77, 20, 128)):
+    for m, k, n in ((300, 144, 512), (128, 656, 512), (1000, 384, 384), (77, 20, 128), (129, 36, 256)):
         x = rng.standard_normal((m, k)).astype(np.float32)
         w = (rng.standard_normal((n, k)) * np.linspace(0.5, 2.0, n)[:, None]).astype(np.float32)
         b = rng.standard_normal(n).astype(np.float32)
-        y = N(ops.linear(G(x), G(w), G(b), relu=False))
+        y = N(ops.linear(G(x), G(w), G(b), relu=False, mma_mode=mm))
         ref = x.astype(np.float64) @ w.astype(np.float64).T + b
         assert rel_err(y, ref) < 2e-6, (m, k, n)
-        yr = N(ops.linear(G(x), G(w), G(b), relu=True))
+        # error relative to sum |x||w| (the quantity fp32 rounding scales with): fp32-class for both modes
+        den = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+        assert (np.abs(y - ref) / den).max() < 4e-7, (mode, m, k, n)
+        yr = N(ops.linear(G(x), G(w), G(b), relu=True, mma_mode=mm))
         assert rel_err(yr, np.maximum(ref, 0)) < 2e-6
+    # wide dynamic range and tiny magnitudes survive the 3-way split (bf16 keeps the fp32 exponent range)
+    x = (rng.standard_normal((256, 384)) * np.logspace(-6, 6, 256)[:, None]).astype(np.float32)
+    w = (rng.standard_normal((128, 384)) * 1e-12).astype(np.float32)
+    y = N(ops.linear(G(x), G(w), None, mma_mode=mm))
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    den = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    assert (np.abs(y - ref) / den).max() < 4e-7
 
 
 def test_a13_ray_features_and_keys(scorer):
