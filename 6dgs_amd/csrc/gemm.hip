@@ -232,14 +232,15 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
                     float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
+  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, nullptr, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
-                       float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
+                       float* key, void* key_planes, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
+                       int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
-  SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key));
+  SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
   const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float)));
   if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;
   const int64_t chunk = chunk_cap < r ? (chunk_cap >= 128 ? chunk_cap / 128 * 128 : chunk_cap) : r;
@@ -250,7 +251,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
   for (int64_t r0 = 0; r0 < r; r0 += chunk) {
     const int64_t m = (r - r0) < chunk ? (r - r0) : chunk;
     // algorithmic work per ray: ray MLP 1 730 560 + k_proj 294 912 FLOP; 36 B in, 1536 B key out
-    SdgProfileScope scope(prof, s, (double)m * (key ? 2025472.0 : 1730560.0), (double)m * (36.0 + 1536.0));
+    SdgProfileScope scope(prof, s, (double)m * ((key || key_planes) ? 2025472.0 : 1730560.0), (double)m * (36.0 + 1536.0));
     int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
     if (st) return st;
     GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
@@ -264,9 +265,12 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
     float* f = feat ? feat + r0 * SIXDGS_D : h2;
     GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID};
     if ((st = launch_linear(g4, w->b4, false, f, SIXDGS_D, s, mma_mode))) return st;
-    if (key) {
+    if (key || key_planes) {
+      // without a caller buffer for fp32 keys the chunk lands in h1 (free after layer 4) and only the planes persist
+      float* kdst = key ? key + r0 * SIXDGS_D : h1;
       GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
-      if ((st = launch_linear(g5, w->bk, false, key + r0 * SIXDGS_D, SIXDGS_D, s, mma_mode))) return st;
+      if ((st = launch_linear(g5, w->bk, false, kdst, SIXDGS_D, s, mma_mode))) return st;
+      if (key_planes && (st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream))) return st;
     }
   }
   return 0;

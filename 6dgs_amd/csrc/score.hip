@@ -102,6 +102,274 @@ __global__ void __launch_bounds__(256, 2) k_logits(LogitsArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 1, v2: bf16x6 on PRE-SPLIT operand planes streamed by LDS-DMA.
+//
+// Operands: q planes [B][256][12 slabs][3 planes][32 k] bf16 and key planes [R][12][3][32] bf16 (2304 B per
+// row; written once by k_split_planes).  Per 32-k slab a workgroup needs 2 x 3 regions of 128 rows x 64 B.
+// Each region is filled by 8 global_load_lds_dwordx4 wave-instructions (1 KiB each, LDS image lane-linear);
+// the per-lane SOURCE address carries an XOR swizzle (16-byte chunk c of row r lands at position
+// c ^ ((r>>2)&3)) so that the ds_read_b128 fragment reads are bank-conflict free without padding.
+// 3-stage ring (144 KiB, one workgroup per CU): the DMA of slab s+2 is issued right after the barrier of
+// slab s, waits are counted (vmcnt(12) keeps the next slab in flight), fragment reads are inline asm so the
+// compiler does not drain the DMA queue in front of them.  No register staging, no split, no ds_write in the
+// main loop: per slab and wave 12 DMA + 24 ds_read_b128 + 48 MFMA (1536 matrix-pipe cycles).
+// Epilogue: logits = acc * (1/sqrt 384) (one rounding instead of torch's true division: <= 1 ulp of a logit,
+// two orders below the accumulation error), row statistics by a 31-exchange transpose-reduce per statistic
+// instead of 32 x 5 shuffles.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+constexpr int kRegion = 8192;            // 128 rows x 64 B
+constexpr int kStageV2 = 6 * kRegion;    // A planes 0..2, B planes 0..2
+constexpr int kRingV2 = 3 * kStageV2;
+constexpr int kRowBytes = 12 * 3 * 64;   // 2304 B of planes per operand row
+constexpr float kInvSqrtD = 0.05103103630798288f;   // (float)(1/sqrt(384))
+
+struct LogitsV2Args {
+  const char* qp;        // [B][256][2304 B]
+  const int* n_tok;
+  const char* kp;        // [R][2304 B]
+  float* logits;
+  float* partial;
+  int64_t r, ldl;
+  int tiles_per_group, n_tiles, n_groups, b0;
+};
+
+__device__ __forceinline__ bf16x8 lds_read_frag(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+// reduce 32 per-lane values across the 32 lanes of each half-wave; afterwards lane (l & 31) == j holds the
+// reduction of slot j.  31 exchanges instead of 32 x 5.
+template <bool IS_MAX>
+__device__ __forceinline__ float transpose_reduce32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int o = 16, n = 16; o >= 1; o >>= 1, n >>= 1) {
+    // lanes with bit `o` set keep the upper half of the remaining slots and send the lower half.  The select is
+    // written as a bit-field insert on the raw bits: a `cond ? v[j+n] : v[j]` form is rewritten by LLVM into a
+    // dynamically indexed vector extract, which lowers to a 32-way compare/select chain per access.
+    const unsigned m = (lane & o) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      const unsigned lo = __float_as_uint(v[j]), hi = __float_as_uint(v[j + n]);
+      const float keep = __uint_as_float((hi & m) | (lo & ~m));
+      const float send = __uint_as_float((lo & m) | (hi & ~m));
+      const float recv = __shfl_xor(send, o, 64);
+      v[j] = IS_MAX ? fmaxf(keep, recv) : keep + recv;
+    }
+  }
+  return v[0];
+}
+// slot j (0..31) of a lane <-> accumulator (tm = j >> 4, r = j & 15); the butterfly above leaves slot
+// bit4 = lane bit4, ..., bit0 = lane bit0, i.e. lane k owns slot k.
+
+__global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
+  __shared__ __attribute__((aligned(1024))) char lds[kRingV2 + 2 * 128 * 8 + 4 * 64 * 4];
+  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds + kRingV2);
+  float* rowmax = reinterpret_cast<float*>(lds + kRingV2 + 2 * 128 * 8);   // [4 waves][64 rows]
+  const int bl = blockIdx.y;
+  const int b = A.b0 + bl;
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = (int)(w >> 1), m_tile = (int)(w & 1u);
+  const int M = A.n_tok[b];
+  const int row0 = m_tile * 128;
+  float* pout = A.partial + (((int64_t)bl * A.n_groups + grp) * kT + row0) * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  float m_run = -INFINITY, s_run = 0.f;
+  const int t_begin = grp * A.tiles_per_group;
+  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+  if (row0 < M && t_begin < t_end) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    // ---- DMA pieces.  Piece i of this wave is 1-KiB block n = 4 i + wave of the stage image, so its region
+    //      (i >> 1: A planes 0..2 for i < 6, B planes 0..2 for i >= 6) is a compile-time property and only the
+    //      position inside the region depends on the wave.  Per lane: a 32-bit byte offset against a
+    //      wave-uniform operand base; the slab stride (192 B) is folded into the address by the unrolled loop.
+    unsigned offA[6], offB[6];
+    int rowB[6];   // per-lane row of key piece i inside the 128-ray tile
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int sub = 4 * (i & 1) + wave;
+      const int chunk = sub * 64 + lane;
+      const int row = chunk >> 2, pos = chunk & 3;
+      const int c = pos ^ ((row >> 2) & 3);
+      const unsigned inrow = (unsigned)(((i >> 1) % 3) * 64 + c * 16);
+      if (i < 6) {
+        const int rr = min(row0 + row, M - 1);        // rows beyond the image's tokens re-read the last valid row
+        offA[i] = (unsigned)rr * kRowBytes + inrow;
+      } else {
+        rowB[i - 6] = row;
+        offB[i - 6] = inrow;
+      }
+    }
+    const char* qbase = A.qp + (int64_t)b * kT * kRowBytes;
+    // issue the 12 pieces of slab `s` of the tile whose key rows start at `kbase` into ring stage `stage`
+    // (both compile-time after unrolling).  `lim` = last valid key row of that tile relative to kbase: rows beyond
+    // the last ray re-read it (their columns are masked in the epilogue).
+    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
+      char* sbase = lds + stage * kStageV2 + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[i] + (unsigned)(s * 192))),
+                                         (lds_ptr_t)(sbase + (i >> 1) * kRegion + (i & 1) * 4096), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const unsigned ob = (unsigned)min(rowB[i], lim) * kRowBytes + offB[i] + (unsigned)(s * 192);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (3 + (i >> 1)) * kRegion + (i & 1) * 4096), 16,
+                                         0, 0);
+      }
+    };
+    auto tile_lim = [&](int tile) {
+      const int64_t left = A.r - (int64_t)tile * kBN - 1;      // >= 0
+      return left < 127 ? (int)left : 127;
+    };
+    // ---- fragment read addresses (relative to the stage base) -----------------------------------------------
+    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + (lane >> 5);
+        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
+        fb[t][ks] = lds0 + 3 * kRegion + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+      }
+
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl;
+    // lane part of a logit address: (4 (lane>>5)) rows + wn*64 + (lane & 31) columns, as a 32-bit element offset
+    const unsigned lane_elem = (unsigned)(4 * (lane >> 5)) * (unsigned)A.ldl + (unsigned)(wn * 64 + (lane & 31));
+    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowBytes;
+    int lim_cur = tile_lim(t_begin);
+    // 12 slabs per tile = 0 mod 3: slab s of every tile lives in ring stage s % 3
+    issue(kcur, lim_cur, 0, 0);
+    issue(kcur, lim_cur, 1, 1);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int64_t col0 = (int64_t)tile * kBN;
+      const bool has_next = tile + 1 < t_end;
+      const char* knext = kcur + (int64_t)kBN * kRowBytes;
+      const int lim_next = has_next ? tile_lim(tile + 1) : 0;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+      for (int s0 = 0; s0 < 12; s0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {     // ring stage of slab s0 + u is u (12 slabs per tile = 0 mod 3)
+          const int sl = s0 + u;
+          // slab sl has landed once at most the 12 pieces of the following slab are still in flight
+          if (sl == 11 && !has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          // everyone is past slab sl-1: its stage is free for slab sl+2 (slabs 12, 13 = slabs 0, 1 of the next tile)
+          if (sl < 10) issue(kcur, lim_cur, sl + 2, (u + 2) % 3);
+          else if (has_next) issue(knext, lim_next, sl - 10, (u + 2) % 3);
+          const unsigned st = (unsigned)(u * kStageV2);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][3], bb[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                a[t][p] = lds_read_frag(fa[t][ks] + st + p * kRegion);
+                bb[t][p] = lds_read_frag(fb[t][ks] + st + p * kRegion);
+              }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], bb[0][PB[q]], acc[0][0], 0, 0, 0);
+              acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], bb[1][PB[q]], acc[0][1], 0, 0, 0);
+              acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], bb[0][PB[q]], acc[1][0], 0, 0, 0);
+              acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], bb[1][PB[q]], acc[1][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+
+      // ---- epilogue: scale, store, per-row (max, sum exp) of this 128-ray tile ----------------------------------
+      // Stores are unconditional: the workspace has 256 rows x ldl (>= R, multiple of 128) columns per image, so
+      // rows >= M and columns >= R land in padding that nobody reads.
+      const bool v0 = col0 + acc_col(wn, 0, lane) < A.r, v1 = col0 + acc_col(wn, 1, lane) < A.r;
+      float mx[32];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // wave-uniform part of the address: row row0 + wm*64 + tm*32 + (r&3) + 8 (r>>2), column col0 (+32 for tn = 1)
+          float* rowp = lg + (int64_t)(row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2)) * A.ldl + col0;
+          const float l0 = acc[tm][0][r] * kInvSqrtD, l1 = acc[tm][1][r] * kInvSqrtD;
+          acc[tm][0][r] = l0;
+          acc[tm][1][r] = l1;
+          rowp[lane_elem] = l0;
+          rowp[lane_elem + 32u] = l1;
+          mx[tm * 16 + r] = fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY);
+        }
+      const float my_max = transpose_reduce32<true>(mx, lane);      // lane k: max of slot k over this wave's 64 columns
+      // broadcast the 32 row maxima of this half-wave back to all of its lanes through LDS
+      float* rmx = rowmax + wave * 64 + (lane >> 5) * 32;
+      rmx[lane & 31] = my_max;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float sm[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float m = rmx[j];
+        const int tm = j >> 4, r = j & 15;
+        const float e0 = v0 ? __expf(acc[tm][0][r] - m) : 0.f, e1 = v1 ? __expf(acc[tm][1][r] - m) : 0.f;
+        sm[j] = (m > -INFINITY) ? e0 + e1 : 0.f;
+      }
+      const float my_sum = transpose_reduce32<false>(sm, lane);
+      {
+        const int j = lane & 31;
+        const int lr = acc_row(wm, j >> 4, j & 15, lane);
+        part[wn][lr][0] = my_max;
+        part[wn][lr][1] = my_sum;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < 128) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float mt = part[h][tid][0], st2 = part[h][tid][1];
+          if (mt > -INFINITY) {
+            const float mn = fmaxf(m_run, mt);
+            s_run = s_run * __expf(m_run - mn) + st2 * __expf(mt - mn);
+            m_run = mn;
+          }
+        }
+      }
+      // `part` is rewritten only after the 12 slab barriers of the next tile
+      kcur = knext;
+      lim_cur = lim_next;
+    }
+  }
+  if (tid < 128) {
+    pout[2 * tid] = m_run;
+    pout[2 * tid + 1] = s_run;
+  }
+}
+
+// fp32 rows [rows][384] (row stride ld) -> bf16 planes [rows][12][3][32]; 8 consecutive k per thread
+__global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ src, int64_t rows, int64_t ld, char* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 48) return;
+  const int64_t row = i / 48;
+  const int k8 = (int)(i - row * 48);
+  const float4 lo = *reinterpret_cast<const float4*>(src + row * ld + k8 * 8);
+  const float4 hi = *reinterpret_cast<const float4*>(src + row * ld + k8 * 8 + 4);
+  split_store8(lo, hi, dst + row * kRowBytes + (k8 >> 2) * 192 + (k8 & 3) * 16);
+}
+
 // merge the per-group partial statistics: stats[b][t] = (max, sumexp)
 __global__ void __launch_bounds__(kT) k_merge_stats(const float* __restrict__ partial, int n_groups, float* __restrict__ stats) {
   const int bl = blockIdx.x, t = threadIdx.x;
@@ -359,7 +627,8 @@ int run_topk(const float* scores, int64_t stride, int64_t r, int batch, int topk
 struct ScorePlan {
   int64_t ldl;
   int n_tiles, tiles_per_group, n_groups;
-  size_t per_image_logits, per_image_partial, per_image_stats, per_image_scores, topk_bytes;
+  size_t per_image_logits, per_image_partial, per_image_stats, per_image_scores, per_image_qplanes, topk_bytes;
+  size_t per_image() const { return per_image_logits + per_image_partial + per_image_stats + per_image_scores + per_image_qplanes; }
 };
 ScorePlan score_plan(int64_t r, int batch, int topk) {
   ScorePlan p;
@@ -371,6 +640,7 @@ ScorePlan score_plan(int64_t r, int batch, int topk) {
   p.per_image_partial = sdg_align((size_t)p.n_groups * kT * 2 * sizeof(float));
   p.per_image_stats = sdg_align((size_t)kT * 2 * sizeof(float));
   p.per_image_scores = sdg_align((size_t)p.ldl * sizeof(float));
+  p.per_image_qplanes = sdg_align((size_t)kT * kRowBytes, 1024);
   p.topk_bytes = topk_plan(r, batch, topk).bytes;
   return p;
 }
@@ -393,19 +663,33 @@ int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* id
 size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
   if (batch < 1) batch = 1;
   const ScorePlan p = score_plan(r, batch, topk);
-  return p.topk_bytes + (size_t)batch * (p.per_image_logits + p.per_image_partial + p.per_image_stats + p.per_image_scores);
+  return p.topk_bytes + (size_t)batch * p.per_image();
 }
 
-int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key, int64_t r,
-                         int topk, float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,
-                         sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
+size_t sixdgs_key_planes_bytes(int64_t r) { return (size_t)(r > 0 ? r : 0) * kRowBytes; }
+
+int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(rows >= 0 && ld >= SIXDGS_D && (ld % 4) == 0);
+  if (rows == 0) return 0;
+  SDG_CHECK_ARG(src && planes && ((uintptr_t)src % 16) == 0 && ((uintptr_t)planes % 16) == 0);
+  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv(rows * 48, 256)), dim3(256), 0, sdg_stream(stream), src, rows, ld,
+                     (char*)planes);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
+                         const void* key_planes, int64_t r, int topk, float* scores, int64_t* idx, float* val, float* row_stats,
+                         void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
-  SDG_CHECK_ARG(q && d_n_tok && (key || r == 0) && idx && val && ws);
+  const bool use_v2 = key_planes != nullptr && mma_mode != SIXDGS_MMA_F32;
+  SDG_CHECK_ARG(q && d_n_tok && (key || use_v2 || r == 0) && idx && val && ws);
+  SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
   SDG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)ws % 256) == 0);
   hipStream_t s = sdg_stream(stream);
   ScorePlan p = score_plan(r, batch, topk);
-  const size_t per_image = p.per_image_logits + p.per_image_partial + p.per_image_stats + p.per_image_scores;
+  const size_t per_image = p.per_image();
   // largest image group whose logits + top-k scratch fit the caller's workspace
   int64_t bg = batch > 65535 ? 65535 : batch;
   while (bg >= 1 && topk_plan(r, (int)bg, topk).bytes + (size_t)bg * per_image > ws_bytes) --bg;
@@ -417,6 +701,7 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
   float* partial = (float*)((char*)logits + (size_t)bg * p.per_image_logits);
   float* stats = (float*)((char*)partial + (size_t)bg * p.per_image_partial);
   float* sc_ws = (float*)((char*)stats + (size_t)bg * p.per_image_stats);
+  char* qplanes = (char*)sc_ws + (size_t)bg * p.per_image_scores;
   const int64_t ldl_img = (int64_t)(p.per_image_logits / sizeof(float)) / kT;  // == p.ldl (alignment keeps it)
   (void)ldl_img;
   for (int b0 = 0; b0 < batch; b0 += (int)bg) {
@@ -430,10 +715,19 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
         SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * SIXDGS_D * 4.0 + tok * 4.0));
-        if (mma_mode == SIXDGS_MMA_F32)
+        if (use_v2) {
+          // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
+          hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,
+                             q + (int64_t)b0 * kT * SIXDGS_D, (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes);
+          LogitsV2Args V = {qplanes, d_n_tok, (const char*)key_planes, logits, partial, r, A.ldl, p.tiles_per_group, p.n_tiles,
+                            p.n_groups, b0};
+          V.qp = qplanes - (int64_t)b0 * kT * kRowBytes;   // the kernel indexes planes by absolute image number
+          hipLaunchKernelGGL(k_logits_v2, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, V);
+        } else if (mma_mode == SIXDGS_MMA_F32) {
           hipLaunchKernelGGL(k_logits<kMmaF32>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
-        else
+        } else {
           hipLaunchKernelGGL(k_logits<kMmaBf16x6>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
+        }
       }
       hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
       hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
@@ -453,8 +747,8 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
 
 int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
                       int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream, nullptr,
-                              SIXDGS_MMA_DEFAULT);
+  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, nullptr, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream,
+                              nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches) {

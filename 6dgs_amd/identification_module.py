@@ -104,15 +104,32 @@ class IdentificationModule(torch.nn.Module):
             self._key_cache = None
         return self._packed
 
-    def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
-        """K[R,384] = k_proj(RayPreprocessor(rays)) -- cached per (ray tensors, weights)."""
+    KEEP_FP32_KEYS_BELOW = 4_000_000   # rays; above, only the bf16 planes are cached (2304 B/ray vs 1536 + 2304)
+
+    def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None):
         w = self.packed_weights(rays_ori.device)
         ident = (rays_ori.data_ptr(), rays_dir.data_ptr(), rays_rgb.data_ptr(), rays_ori.shape[0], rays_ori._version,
-                 rays_dir._version, rays_rgb._version, self._packed_key)
+                 rays_dir._version, rays_rgb._version, self._packed_key, ops.get_mma_mode())
         if self._key_cache is None or self._key_cache_id != ident:
-            _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
-            self._key_cache, self._key_cache_id = key, ident
+            r = rays_ori.shape[0]
+            planes_mode = ops.get_mma_mode() != ops.MMA_F32
+            keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
+            if planes_mode:
+                _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True)
+            else:
+                _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
+                planes = None
+            self._key_cache, self._key_cache_id = {"key": key, "planes": planes}, ident
         return self._key_cache
+
+    def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
+        """K[R,384] = k_proj(RayPreprocessor(rays)) -- computed once per (ray tensors, weights) and cached, as fp32
+        and/or as the bf16 planes the fast scorer kernel streams."""
+        c = self._ensure_keys(rays_ori, rays_dir, rays_rgb, profile)
+        if c["key"] is None:   # large scene: fp32 copy on request only
+            _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, self.packed_weights(rays_ori.device))
+            return key
+        return c["key"]
 
     def ray_features(self, rays_ori, rays_dir, rays_rgb) -> torch.Tensor:
         """RayPreprocessor.forward (ray_preprocessor.py:36-46): [R,384] features (not cached)."""
@@ -147,13 +164,13 @@ class IdentificationModule(torch.nn.Module):
                      want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
                      profile=None):
         """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
-        key = self.ray_keys(rays_ori, rays_dir, rays_rgb)
+        kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
         tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
         q = ops.q_proj(tokens, n_tok, w)
-        idx, val, scores, _ = ops.score_topk(q, n_tok, key, rays_to_output, want_scores=want_scores, workspace=workspace,
+        idx, val, scores, _ = ops.score_topk(q, n_tok, kc["key"], rays_to_output, want_scores=want_scores, workspace=workspace,
                                              images_in_flight=images_in_flight, profile=profile,
-                                             n_tok_host=[int(t.shape[0]) for t in token_list])
+                                             n_tok_host=[int(t.shape[0]) for t in token_list], key_planes=kc["planes"])
         return idx, val, scores
 
     @torch.no_grad()

@@ -256,8 +256,18 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None) -> 
     return y
 
 
+def split_planes(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows,384] -> bf16 planes as uint8 [rows, 2304] ([12 slabs][3 planes][32 k] per row)."""
+    x = _f32(x)
+    _need_gpu(x)
+    out = torch.empty(x.shape[0], 2304, dtype=torch.uint8, device=x.device)
+    check(_lib.load().sixdgs_split_planes(_p(x), x.shape[0], x.stride(0), _p(out), _stream()), "split_planes")
+    return out
+
+
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
-             workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None):
+             workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False):
+    """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes uint8 [R,2304])."""
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
     lib = _lib.load()
@@ -265,11 +275,12 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     dev = ori.device
     feat = torch.empty(r, D, device=dev) if want_feat else None
     key = torch.empty(r, D, device=dev) if want_key else None
+    planes = torch.empty(r, 2304, dtype=torch.uint8, device=dev) if want_planes else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(ws), ws.numel(), _stream(),
-                                 profile.ref if profile is not None else None, _mma_mode), "ray_keys")
-    return feat, key
+    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(ws), ws.numel(),
+                                 _stream(), profile.ref if profile is not None else None, _mma_mode), "ray_keys")
+    return (feat, key, planes) if want_planes else (feat, key)
 
 
 def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -298,13 +309,16 @@ def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100) -> int:
     return int(_lib.load().sixdgs_score_topk_workspace_bytes(int(r), int(batch), int(topk)))
 
 
-def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: int = 100, want_scores: bool = True,
+def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], topk: int = 100, want_scores: bool = True,
                want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
-               profile: Optional["KernelProfile"] = None, n_tok_host=None):
-    q, key = _f32(q), _f32(key)
-    _need_gpu(q, key, n_tok)
+               profile: Optional["KernelProfile"] = None, n_tok_host=None, key_planes: Optional[torch.Tensor] = None):
+    """key: fp32 [R,384] and/or key_planes: uint8 [R,2304] (bf16 planes; selects the DMA-fed kernel unless MMA_F32)."""
+    q = _f32(q)
+    key = _f32(key) if key is not None else None
+    _need_gpu(q, key, n_tok, key_planes)
     lib = _lib.load()
-    b, r, dev = q.shape[0], key.shape[0], q.device
+    r = key.shape[0] if key is not None else key_planes.shape[0]
+    b, dev = q.shape[0], q.device
     idx = torch.empty(b, topk, dtype=torch.int64, device=dev)
     val = torch.empty(b, topk, device=dev)
     scores = torch.empty(b, r, device=dev) if want_scores else None
@@ -315,7 +329,7 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: torch.Tensor, topk: in
     h_n = None
     if profile is not None and n_tok_host is not None:
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
-    check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
+    check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
                                    _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,
                                    _mma_mode), "score_topk")
     return idx, val, scores, stats

@@ -92,7 +92,7 @@ def main():
     R = int(ori.shape[0])
     kprof = ops.KernelProfile()
     t0 = time.time()
-    idm.ray_keys(ori, dr, rgb, profile=kprof)
+    idm._ensure_keys(ori, dr, rgb, profile=kprof)
     torch.cuda.synchronize()
     t_keys = time.time() - t0
     k_ms, k_fl, _, _ = kprof.collect()
@@ -154,7 +154,7 @@ def main():
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0
         out["roofline"] = {
-            "kernel": "k_logits (q.K^T fp32 MFMA tile + online row stats, logits stored once)",
+            "kernel": "k_logits_v2 (q.K^T as 3-plane bf16 split x 6 MFMA terms, fp32-equivalent; LDS-DMA ring; online row stats; logits stored once)",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "launches": l_n, "avg_launch_ms": round(l_ms / max(l_n, 1), 4),
@@ -167,6 +167,10 @@ def main():
     dd.barrier()
 
 
+def ops_mod():
+    return importlib.import_module("6dgs_amd.ops")
+
+
 def cpu_baseline(args, idm, ori, dr, rgb, R, sol):
     """The CPU oracle (oracle/sixdgs_oracle.c, OpenMP, all host cores) on a bounded sample of the same workload:
     the per-pose path (q_proj, 3-pass softmax scorer, top-100, pose tail) over the first `cpu_sample_rays` rays
@@ -174,7 +178,8 @@ def cpu_baseline(args, idm, ori, dr, rgb, R, sol):
     from oracle import oracle as O
     O.build()
     rs = int(min(args.cpu_sample_rays, R))
-    key = idm.ray_keys(ori, dr, rgb)[:rs].cpu().numpy()
+    _, key = ops_mod().ray_keys(ori[:rs].contiguous(), dr[:rs].contiguous(), rgb[:rs].contiguous(), idm.packed_weights(ori.device))
+    key = key.cpu().numpy()
     o_np, d_np = ori[:rs].cpu().numpy(), dr[:rs].cpu().numpy()
     tok = sol["tokens"][0].cpu().numpy()
     up = sol["up"][0].cpu().numpy()

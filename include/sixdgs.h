@@ -173,9 +173,15 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk);
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
                     float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing the whole MLP chain of each chunk (2 025 472 algorithmic FLOP per ray) into `prof` */
+/* key_planes (optional, sixdgs_key_planes_bytes(r) bytes): the keys pre-split into three bf16 planes,
+ * [R][12 k-slabs][3 planes][32] -- the operand format of the DMA-fed bf16x6 scorer kernel.  With key == NULL only
+ * the planes are kept (2304 B per ray instead of 1536 B fp32). */
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
-                       float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
-                       int mma_mode);
+                       float* feat, float* key, void* key_planes, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
+                       sixdgs_profile* prof, int mma_mode);
+size_t sixdgs_key_planes_bytes(int64_t r);
+/* fp32 rows [rows][384] (row stride ld floats) -> bf16 planes [rows][12][3][32] (x = h + m + l exactly) */
+int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream);
 
 /* generic fp32 MFMA GEMM used by the above: y[M,N] = act(x[M,K] . w[N,K]^T + b), K % 16 == 0,
  * N % 128 == 0, ldx/ldw/ldy in floats and multiples of 4. */
@@ -204,10 +210,11 @@ int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, in
                       float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,
                       size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing each launch of the logits kernel (2*T*384 algorithmic FLOP per ray and image) into `prof` */
+/* key_planes != NULL (and mma_mode != F32) selects the DMA-fed bf16x6 kernel; `key` (fp32) may then be NULL. */
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy, for the FLOP count*/,
-                         int batch, const float* key, int64_t r, int topk, float* scores, int64_t* idx, float* val,
-                         float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
-                         int mma_mode);
+                         int batch, const float* key, const void* key_planes, int64_t r, int topk, float* scores,
+                         int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
+                         sixdgs_profile* prof, int mma_mode);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

@@ -204,9 +204,11 @@ def scorer(request, ops, oracle, golden, syn):
     sd = syn.make_scorer_state_dict(0)
     rays = syn.make_rays(4096, 0)
     w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
-    feat, key = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True)
+    feat, key, planes = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True, want_planes=True)
     ofeat, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
-    return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey)
+    # bf16x6 mode scores through the DMA-fed kernel on the pre-split planes; f32 mode on the fp32 keys
+    return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey, mode=request.param,
+                planes=planes if request.param == "bf16x6" else None)
 
 
 def test_a12_ray_encode(ops, oracle, scorer):
@@ -270,7 +272,7 @@ def test_a14_a15_score_topk(ops, oracle, scorer, syn, tag, T, scale):
     oq = oracle.q_proj(tok, scorer["sd"])
     assert rel_err(N(q)[0, :T], oq) < 5e-6
     assert (N(q)[0, T:] == 0).all()
-    idx, val, scores, stats = ops.score_topk(q, n_tok, scorer["key"], 100, want_stats=True)
+    idx, val, scores, stats = ops.score_topk(q, n_tok, scorer["key"], 100, want_stats=True, key_planes=scorer["planes"])
     s = N(scores)[0]
     # values: 1e-5 relative against the reference's fp32 result and against the oracle
     assert rel_err(s, g[f"{tag}_scores"]) < 1e-5
@@ -299,15 +301,39 @@ def test_score_topk_batched_and_grouped(ops, scorer, syn):
     toks = [syn.make_tokens(t, 10 + i, 40.0) for i, t in enumerate((256, 137, 1, 200, 0))]
     tokens, n_tok = ops.pad_tokens([G(t) for t in toks], "cuda")
     q = ops.q_proj(tokens, n_tok, scorer["w"])
-    idx, val, sc, _ = ops.score_topk(q, n_tok, scorer["key"], 100)
-    idx1, val1, sc1, _ = ops.score_topk(q, n_tok, scorer["key"], 100, images_in_flight=1)
+    kp = scorer["planes"]
+    idx, val, sc, _ = ops.score_topk(q, n_tok, scorer["key"], 100, key_planes=kp)
+    idx1, val1, sc1, _ = ops.score_topk(q, n_tok, scorer["key"], 100, images_in_flight=1, key_planes=kp)
     assert torch.equal(idx, idx1) and torch.equal(val, val1) and torch.equal(sc, sc1)
     for i in range(4):
         qi = q[i:i + 1].contiguous()
-        ii, vi, si, _ = ops.score_topk(qi, n_tok[i:i + 1].contiguous(), scorer["key"], 100)
+        ii, vi, si, _ = ops.score_topk(qi, n_tok[i:i + 1].contiguous(), scorer["key"], 100, key_planes=kp)
         assert torch.equal(ii[0], idx[i]) and torch.equal(si[0], sc[i])
     assert (N(sc)[4] == 0).all()                          # no tokens -> all-zero scores (empty sum)
     assert (N(idx)[4] == np.arange(100)).all()            # all ties -> lowest indices
+
+
+def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
+    """x == h + m + l exactly for the 3-plane bf16 split; the three logits kernels (fp32 MFMA, bf16x6 with
+    on-the-fly split, bf16x6 DMA-fed on pre-split planes) agree to fp32 rounding and in their top-100."""
+    key = scorer["key"]
+    pl = ops.split_planes(key).cpu().numpy().reshape(-1, 12, 3, 32, 2)
+    u16 = (pl[..., 0].astype(np.uint32) | (pl[..., 1].astype(np.uint32) << 8)) << 16
+    parts = u16.view(np.float32).astype(np.float64)                       # [R,12,3,32]
+    recon = parts.sum(axis=2).reshape(-1, 384)
+    assert (recon == N(key).astype(np.float64)).all()
+    assert (np.abs(parts[:, :, 1]) <= np.abs(parts[:, :, 0]) * 2.0 ** -8 + 1e-45).all()
+    tok = syn.make_tokens(256, 5, 40.0)
+    tokens, n_tok = ops.pad_tokens([G(tok)], "cuda")
+    q = ops.q_proj(tokens, n_tok, scorer["w"])
+    res = {}
+    for name, mode, kp in (("f32", ops.MMA_F32, None), ("b6", ops.MMA_BF16X6, None), ("b6dma", ops.MMA_BF16X6, ops.split_planes(key))):
+        ops.set_mma_mode(mode)
+        res[name] = ops.score_topk(q, n_tok, key, 100, key_planes=kp)
+    ops.set_mma_mode(ops.MMA_BF16X6 if scorer["mode"] == "bf16x6" else ops.MMA_F32)
+    for name in ("b6", "b6dma"):
+        assert rel_err(N(res[name][2]), N(res["f32"][2])) < 5e-6, name
+        assert (N(res[name][0]) == N(res["f32"][0])).all(), name
 
 
 def test_topk_ties_short_and_large(ops, oracle):
