@@ -34,6 +34,29 @@ class CameraDirectionPredictor(torch.nn.Module):
         """image_features [384,16,16] -> [3]   or batched [B,384,16,16] -> [B,3]"""
         single = image_features.dim() == 3
         x = image_features[None] if single else image_features
-        x = self.dim_reducer2(self.dim_reducer1(x))
-        y = self.mlp(x.reshape(x.shape[0], -1))
+        if x.is_cuda and not torch.is_grad_enabled():
+            y = self._forward_gemm(x)
+        else:
+            x = self.dim_reducer2(self.dim_reducer1(x))
+            y = self.mlp(x.reshape(x.shape[0], -1))
         return y[0] if single else y
+
+    def _forward_gemm(self, x):
+        """Inference on the GPU: each valid convolution of the 16x16 map is im2col (F.unfold, same (c, kh, kw) order as
+        conv.weight.view(out, -1)) + the library's MFMA `linear` with the bias/ReLU epilogue.  MIOpen has no tuned fp32
+        solver for 384-channel 5x5 on 16x16 and falls back to naive_conv (2.7 ms per image in the round-1 trace)."""
+        from . import ops
+
+        b = x.shape[0]
+        for seq in (self.dim_reducer1, self.dim_reducer2):
+            for layer in seq:
+                if not isinstance(layer, torch.nn.Conv2d):
+                    continue
+                k = layer.kernel_size[0]
+                ho, wo = x.shape[2] - k + 1, x.shape[3] - k + 1
+                cols = torch.nn.functional.unfold(x, k)                       # [B, C*k*k, ho*wo]
+                a = cols.transpose(1, 2).reshape(b * ho * wo, -1).contiguous()
+                y = ops.linear(a, layer.weight.reshape(layer.weight.shape[0], -1), layer.bias, relu=True)
+                x = y.reshape(b, ho, wo, -1).permute(0, 3, 1, 2).contiguous()
+        h = ops.linear(x.reshape(b, -1).contiguous(), self.mlp[0].weight, self.mlp[0].bias, relu=True)
+        return ops.linear(h, self.mlp[2].weight, self.mlp[2].bias, relu=False)

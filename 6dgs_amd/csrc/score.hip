@@ -9,6 +9,8 @@
 // before any column sum can be formed, so the [T, R] logits are written once to a caller-provided
 // workspace (1 KB per ray and image, token-major) instead of recomputing the contraction in a second
 // pass: at R = 32 M that is 64 GB of extra HBM traffic (~12 ms) against ~40 ms of fp32 MFMA work.
+#include <stdlib.h>
+
 #include "gemm_kernel.h"
 
 using namespace sdg;
@@ -166,6 +168,9 @@ __device__ __forceinline__ float transpose_reduce32(float (&v)[32], int lane) {
 // slot j (0..31) of a lane <-> accumulator (tm = j >> 4, r = j & 15); the butterfly above leaves slot
 // bit4 = lane bit4, ..., bit0 = lane bit0, i.e. lane k owns slot k.
 
+// ABL (debug ablation bits, 0 in production): 1 = Q-plane DMA only for the first tile, 2 = no epilogue,
+// 4 = no MFMA, 8 = key DMA only for the first tile.  Results are wrong for ABL != 0; timing only.
+template <int ABL>
 __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
   __shared__ __attribute__((aligned(1024))) char lds[kRingV2 + 2 * 128 * 8 + 4 * 64 * 4];
   float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds + kRingV2);
@@ -210,18 +215,26 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
     // issue the 12 pieces of slab `s` of the tile whose key rows start at `kbase` into ring stage `stage`
     // (both compile-time after unrolling).  `lim` = last valid key row of that tile relative to kbase: rows beyond
     // the last ray re-read it (their columns are masked in the epilogue).
-    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
+    bool first_tile = true;
+    // one DMA piece (i = 0..5: key pieces from HBM first, i = 6..11: q-plane pieces, L2 hits) of slab `s` of the tile
+    // whose key rows start at `kbase` into ring stage `stage`; s, stage, i are compile-time after unrolling.  `lim` =
+    // last valid key row of that tile relative to kbase: rows beyond the last ray re-read it (masked in the epilogue).
+    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {
       char* sbase = lds + stage * kStageV2 + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[i] + (unsigned)(s * 192))),
-                                         (lds_ptr_t)(sbase + (i >> 1) * kRegion + (i & 1) * 4096), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      if (i < 6) {
         const unsigned ob = (unsigned)min(rowB[i], lim) * kRowBytes + offB[i] + (unsigned)(s * 192);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (3 + (i >> 1)) * kRegion + (i & 1) * 4096), 16,
-                                         0, 0);
+        if (!(ABL & 8) || first_tile)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (3 + (i >> 1)) * kRegion + (i & 1) * 4096), 16, 0, 0);
+      } else {
+        const int k = i - 6;
+        if (!(ABL & 1) || first_tile)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[k] + (unsigned)(s * 192))),
+                                           (lds_ptr_t)(sbase + (k >> 1) * kRegion + (k & 1) * 4096), 16, 0, 0);
       }
+    };
+    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) issue_piece(kbase, lim, s, stage, i);
     };
     auto tile_lim = [&](int tile) {
       const int64_t left = A.r - (int64_t)tile * kBN - 1;      // >= 0
@@ -244,9 +257,43 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
     const unsigned lane_elem = (unsigned)(4 * (lane >> 5)) * (unsigned)A.ldl + (unsigned)(wn * 64 + (lane & 31));
     const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowBytes;
     int lim_cur = tile_lim(t_begin);
-    // 12 slabs per tile = 0 mod 3: slab s of every tile lives in ring stage s % 3
+    // 12 slabs per tile = 0 mod 3: slab s of every tile lives in ring stage s % 3.
+    // Schedule (fragment registers double-buffered, so the LDS latency of the next k-step hides under the MFMAs of
+    // the current one):   B(k) = { wait slab k landed; barrier; issue DMA of slab k+2 }
+    //   B(0); F0 <- (0, ks0); wait
+    //   for sl: F1 <- (sl, ks1); MFMA(F0); wait; B(sl+1); F0 <- (sl+1, ks0); MFMA(F1); wait
+    // B(12) / F0(12) are B(0) / F0(0) of the next tile.  When a wave reaches B(sl+1) all of its reads of slab sl have
+    // completed (the wait before it), so after the barrier the stage of slab sl may be refilled with slab sl+3.
+    auto B = [&](const char* kb, int lim, const int sl_local, const bool last_wait) {
+      // sl_local: slab index within ITS tile (0..11) whose arrival is awaited; issues slab sl_local + 2 of the same
+      // tile, or slabs 0/1 of the following tile when sl_local is 10/11.
+      if (last_wait || (ABL & 9)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      (void)kb; (void)lim;
+    };
+    bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
+    auto read_frags = [&](bf16x8 (&fa_)[2][3], bf16x8 (&fb_)[2][3], const int stage, const int ks) {
+      const unsigned st = (unsigned)(stage * kStageV2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa_[t][p] = lds_read_frag(fa[t][ks] + st + p * kRegion);
+          fb_[t][p] = lds_read_frag(fb[t][ks] + st + p * kRegion);
+        }
+    };
+    auto wait_lds = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
     issue(kcur, lim_cur, 0, 0);
     issue(kcur, lim_cur, 1, 1);
+    // B(0) of the first tile
+    B(kcur, lim_cur, 0, false);
+    issue(kcur, lim_cur, 2, 2);
+    read_frags(f0a, f0b, 0, 0);
+    wait_lds();
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int64_t col0 = (int64_t)tile * kBN;
       const bool has_next = tile + 1 < t_end;
@@ -260,43 +307,74 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+      // 24 MFMAs on fragment set (xa, xb) with up to 24 "side" instructions interleaved one per MFMA slot: the 12
+      // fragment reads of the NEXT k-step and, optionally, the 12 DMA pieces of a later slab.  Issuing those as bursts
+      // in front of the MFMA block stalls the in-order wave on the LDS / TA queues while the matrix pipe idles.
+      auto mfma_step = [&](bf16x8 (&xa)[2][3], bf16x8 (&xb)[2][3], bf16x8 (&na)[2][3], bf16x8 (&nb)[2][3], const bool do_read,
+                           const int rstage, const int rks, const bool do_dma, const char* dkb, const int dlim, const int ds,
+                           const int dstage) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        const unsigned st = (unsigned)(rstage * kStageV2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+          for (int z = 0; z < 4; ++z) {
+            const int slot = q * 4 + z;        // 0..23
+            const int tm = z >> 1, tn = z & 1;
+            if (!(ABL & 4))
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[tm][PA[q]], xb[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+            if (do_read && !(ABL & 16) && (slot & 1) == 0) {  // 12 reads on the even slots
+              const int ridx = slot >> 1;      // 0..11: (operand, t, p)
+              const int op = ridx / 6, t = (ridx % 6) / 3, pp = ridx % 3;
+              if (op == 0) na[t][pp] = lds_read_frag(fa[t][rks] + st + pp * kRegion);
+              else nb[t][pp] = lds_read_frag(fb[t][rks] + st + pp * kRegion);
+            }
+            if (do_dma && (slot & 1) == 1) issue_piece(dkb, dlim, ds, dstage, slot >> 1);   // 12 pieces on the odd slots
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (ABL & 4) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p2 = 0; p2 < 3; ++p2) asm volatile("" ::"v"(xa[t][p2]), "v"(xb[t][p2]));
+        }
+      };
+
       for (int s0 = 0; s0 < 12; s0 += 3) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {     // ring stage of slab s0 + u is u (12 slabs per tile = 0 mod 3)
+        for (int u = 0; u < 3; ++u) {     // slab sl = s0 + u sits in ring stage u
           const int sl = s0 + u;
-          // slab sl has landed once at most the 12 pieces of the following slab are still in flight
-          if (sl == 11 && !has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          // everyone is past slab sl-1: its stage is free for slab sl+2 (slabs 12, 13 = slabs 0, 1 of the next tile)
-          if (sl < 10) issue(kcur, lim_cur, sl + 2, (u + 2) % 3);
-          else if (has_next) issue(knext, lim_next, sl - 10, (u + 2) % 3);
-          const unsigned st = (unsigned)(u * kStageV2);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[2][3], bb[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int p = 0; p < 3; ++p) {
-                a[t][p] = lds_read_frag(fa[t][ks] + st + p * kRegion);
-                bb[t][p] = lds_read_frag(fb[t][ks] + st + p * kRegion);
-              }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], bb[0][PB[q]], acc[0][0], 0, 0, 0);
-              acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][PA[q]], bb[1][PB[q]], acc[0][1], 0, 0, 0);
-              acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], bb[0][PB[q]], acc[1][0], 0, 0, 0);
-              acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][PA[q]], bb[1][PB[q]], acc[1][1], 0, 0, 0);
-            }
+          // k-step 0 of slab sl; the reads of its k-step 1 ride along
+          mfma_step(f0a, f0b, f1a, f1b, true, u, 1, false, nullptr, 0, 0, 0);
+          wait_lds();
+          // B(sl + 1): the next slab (of this tile, or slab 0 of the next one) has landed for everyone
+          const bool more = sl < 11 || has_next;
+          if (more) {
+            const bool lastw = (sl == 10) && !has_next;   // slab 11 of the final tile: nothing younger in flight
+            B(kcur, lim_cur, sl + 1, lastw);
+            if (sl >= 9) first_tile = false;
           }
+          // k-step 1 of slab sl; riding along: reads of (sl+1, ks0) and the DMA of slab sl + 3 into this slab's stage
+          const bool dma_same = more && (sl + 3 < 12);
+          const bool dma_next = more && (sl + 3 >= 12) && has_next;
+          if (dma_same) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 3, 0, true, kcur, lim_cur, sl + 3, u);
+          else if (dma_next) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 3, 0, true, knext, lim_next, sl + 3 - 12, u);
+          else mfma_step(f1a, f1b, f0a, f0b, more, (u + 1) % 3, 0, false, nullptr, 0, 0, 0);
+          wait_lds();
         }
       }
 
+      if (ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        kcur = knext;
+        lim_cur = lim_next;
+        continue;
+      }
       // ---- epilogue: scale, store, per-row (max, sum exp) of this 128-ray tile ----------------------------------
       // Stores are unconditional: the workspace has 256 rows x ldl (>= R, multiple of 128) columns per image, so
       // rows >= M and columns >= R land in padding that nobody reads.
@@ -722,7 +800,26 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
           LogitsV2Args V = {qplanes, d_n_tok, (const char*)key_planes, logits, partial, r, A.ldl, p.tiles_per_group, p.n_tiles,
                             p.n_groups, b0};
           V.qp = qplanes - (int64_t)b0 * kT * kRowBytes;   // the kernel indexes planes by absolute image number
-          hipLaunchKernelGGL(k_logits_v2, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, V);
+          const dim3 gg((unsigned)(p.n_groups * 2), (unsigned)nb);
+#ifdef SIXDGS_ABLATION   // timing experiments only (tools/ablate_logits.py builds a private copy of the library with it)
+          const char* ab = getenv("SIXDGS_DEBUG_ABLATE");
+          const int abl = ab ? atoi(ab) : 0;
+          switch (abl) {
+            case 0: hipLaunchKernelGGL(k_logits_v2<0>, gg, dim3(256), 0, s, V); break;
+            case 1: hipLaunchKernelGGL(k_logits_v2<1>, gg, dim3(256), 0, s, V); break;
+            case 2: hipLaunchKernelGGL(k_logits_v2<2>, gg, dim3(256), 0, s, V); break;
+            case 4: hipLaunchKernelGGL(k_logits_v2<4>, gg, dim3(256), 0, s, V); break;
+            case 6: hipLaunchKernelGGL(k_logits_v2<6>, gg, dim3(256), 0, s, V); break;
+            case 8: hipLaunchKernelGGL(k_logits_v2<8>, gg, dim3(256), 0, s, V); break;
+            case 9: hipLaunchKernelGGL(k_logits_v2<9>, gg, dim3(256), 0, s, V); break;
+            case 11: hipLaunchKernelGGL(k_logits_v2<11>, gg, dim3(256), 0, s, V); break;
+            case 18: hipLaunchKernelGGL(k_logits_v2<18>, gg, dim3(256), 0, s, V); break;
+            case 27: hipLaunchKernelGGL(k_logits_v2<27>, gg, dim3(256), 0, s, V); break;
+            default: return SIXDGS_E_BADARG;
+          }
+#else
+          hipLaunchKernelGGL(k_logits_v2<0>, gg, dim3(256), 0, s, V);
+#endif
         } else if (mma_mode == SIXDGS_MMA_F32) {
           hipLaunchKernelGGL(k_logits<kMmaF32>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
         } else {

@@ -1,0 +1,32 @@
+"""Timing-only ablations of the DMA-fed logits kernel (SIXDGS_DEBUG_ABLATE): which part of a tile costs what."""
+import importlib, os, subprocess, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# private build of the library with the ablation switches compiled in (never the shipped .so)
+abl_so = os.path.join(ROOT, "gpurun_out", "lib6dgs_hip_ablation.so")
+if not os.path.exists(abl_so):
+    os.makedirs(os.path.dirname(abl_so), exist_ok=True)
+    csrc = os.path.join(ROOT, "6dgs_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DSIXDGS_ABLATION",
+                           "-shared", *[os.path.join(csrc, f) for f in ("geometry.hip", "gemm.hip", "score.hip", "pose.hip")], "-o", abl_so])
+L = importlib.import_module("6dgs_amd._lib")
+L.LIB_PATH = abl_so
+ops = importlib.import_module("6dgs_amd.ops")
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 6_400_000
+torch.manual_seed(0)
+key = torch.randn(R, 384, device="cuda")
+planes = ops.split_planes(key)
+del key
+q = torch.randn(2, 256, 384, device="cuda")
+n_tok = torch.full((2,), 256, dtype=torch.int32, device="cuda")
+ws = torch.empty(ops.score_topk_workspace_bytes(R, 2, 100), dtype=torch.uint8, device="cuda")
+names = {0: "full", 1: "Q DMA first tile only", 8: "key DMA first tile only", 9: "no DMA after first tile", 2: "no epilogue",
+         4: "no MFMA", 6: "no MFMA, no epilogue", 11: "no DMA, no epilogue", 27: "MFMA + barriers only (no DMA/reads/epilogue)", 18: "no frag reads, no epilogue"}
+for abl in (0, 1, 8, 9, 2, 4, 11, 27):
+    os.environ["SIXDGS_DEBUG_ABLATE"] = str(abl)
+    for it in range(2):
+        prof = ops.KernelProfile()
+        ops.score_topk(q, n_tok, None, 100, want_scores=False, workspace=ws, key_planes=planes, profile=prof, n_tok_host=[256, 256])
+        ms, fl, by, n = prof.collect()
+    print(f"ABL={abl:3d} {names[abl]:34s} {ms:8.2f} ms   {fl / ms / 1e9:7.1f} TFLOP/s-eq   per WG-tile {ms * 1e3 * 256 / (R / 128 * 4):6.2f} us")
