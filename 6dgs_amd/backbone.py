@@ -173,10 +173,16 @@ class BackboneWrapper(torch.nn.Module):
                              antialias=True)
 
     def preprocess(self, img, mask):
-        """img [H,W,3] fp32, mask [H,W] bool -> (norm_img [1,3,224,224], token mask [16,16] bool)"""
+        """img [H,W,3] fp32, mask [H,W] bool (or None = all pixels valid) -> (norm_img [1,3,224,224], token mask [16,16]
+        bool or None).  An all-ones mask stays all-ones through the bilinear resizes (> 0.1 everywhere, backbone.py:88),
+        so the three resize kernels are skipped for RGB images."""
         norm_img = self.transformations(img[None].permute(0, 3, 1, 2))
-        mask_img = self.mask_transformations(mask[None, None] * 1.0)[0, 0] > 0.1
+        mask_img = None if mask is None else self.mask_transformations(mask[None, None] * 1.0)[0, 0] > 0.1
         return norm_img, mask_img
+
+    def preprocess_batch(self, imgs):
+        """[n,H,W,3] fp32 (same size, no alpha) -> [n,3,224,224]"""
+        return self.transformations(imgs.permute(0, 3, 1, 2))
 
     def position_encoding(self, dtype, device):
         key = (dtype, str(device))
@@ -190,12 +196,20 @@ class BackboneWrapper(torch.nn.Module):
         return tok.reshape(tok.shape[0], self.backbone_wh[0], self.backbone_wh[1], self.img_num_features)
 
     def assemble(self, feat_hw, mask_img):
-        """one image: feat_hw [16,16,384], mask [16,16] -> (tokens+pe [T,398], tokens [T,384], fmap [384,16,16])"""
+        """one image: feat_hw [16,16,384], mask [16,16] (None = all) -> (tokens+pe [T,398], tokens [T,384], fmap [384,16,16])"""
         pe = self.position_encoding(feat_hw.dtype, feat_hw.device)
         with_pe = torch.cat([feat_hw, pe], dim=-1)
+        if mask_img is None:
+            return with_pe.reshape(-1, with_pe.shape[-1]), feat_hw.reshape(-1, feat_hw.shape[-1]), feat_hw.permute(2, 0, 1)
         return with_pe[mask_img].view(-1, with_pe.shape[-1]), feat_hw[mask_img].view(-1, feat_hw.shape[-1]), feat_hw.permute(2, 0, 1)
 
-    def forward(self, img, mask):
+    def assemble_batch(self, feats):
+        """[n,16,16,384] (all tokens valid) -> (tokens+pe [n,256,398], fmaps [n,384,16,16])"""
+        pe = self.position_encoding(feats.dtype, feats.device)
+        with_pe = torch.cat([feats, pe[None].expand(feats.shape[0], -1, -1, -1)], dim=-1)
+        return with_pe.reshape(feats.shape[0], -1, with_pe.shape[-1]), feats.permute(0, 3, 1, 2)
+
+    def forward(self, img, mask=None):
         norm_img, mask_img = self.preprocess(img, mask)
         feat = self.features_from_norm(norm_img)[0]
         return self.assemble(feat, mask_img)

@@ -136,14 +136,25 @@ class IdentificationModule(torch.nn.Module):
         feat, _ = ops.ray_keys(rays_ori, rays_dir, rays_rgb, self.packed_weights(rays_ori.device), want_feat=True, want_key=False)
         return feat
 
+    def _full_ntok(self, b, device):
+        c = getattr(self, "_ntok_cache", None)
+        if c is None or c.shape[0] < b or c.device != device:
+            self._ntok_cache = c = torch.full((max(b, 64),), ops.MAX_TOKENS, dtype=torch.int32, device=device)
+        return c[:b]
+
     def invalidate_caches(self):
         self._packed = self._key_cache = None
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
-    def image_tokens(self, imgs: Sequence[torch.Tensor], masks: Sequence[torch.Tensor]):
-        """Batch of images (any sizes) -> list of (tokens+pe [T,398], fmap [384,16,16])."""
+    def image_tokens(self, imgs: Sequence[torch.Tensor], masks: Sequence[Optional[torch.Tensor]]):
+        """Batch of images (any sizes; mask None = no alpha channel) -> (tokens, fmaps [B,384,16,16]) where tokens is a
+        list of [T_i,398] tensors, or ONE [B,256,398] tensor when every image keeps all 256 tokens and all share a size
+        (the common case: one launch sequence for the whole batch instead of one per image)."""
         bw = self.backbone_wrapper
+        if all(m is None for m in masks) and all(i.shape == imgs[0].shape for i in imgs):
+            feats = bw.features_from_norm(bw.preprocess_batch(torch.stack(list(imgs))))
+            return bw.assemble_batch(feats)
         pre = [bw.preprocess(i, m) for i, m in zip(imgs, masks)]
         feats = bw.features_from_norm(torch.cat([p[0] for p in pre], dim=0))
         toks, fmaps = [], []
@@ -166,11 +177,17 @@ class IdentificationModule(torch.nn.Module):
         """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
         kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
-        tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
+        if torch.is_tensor(token_list):          # pre-batched [B,256,398]: every image has all 256 tokens
+            tokens = token_list.contiguous()
+            n_host = [tokens.shape[1]] * tokens.shape[0]
+            n_tok = self._full_ntok(tokens.shape[0], tokens.device)
+        else:
+            tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
+            n_host = [int(t.shape[0]) for t in token_list]
         q = ops.q_proj(tokens, n_tok, w)
         idx, val, scores, _ = ops.score_topk(q, n_tok, kc["key"], rays_to_output, want_scores=want_scores, workspace=workspace,
-                                             images_in_flight=images_in_flight, profile=profile,
-                                             n_tok_host=[int(t.shape[0]) for t in token_list], key_planes=kc["planes"])
+                                             images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
+                                             key_planes=kc["planes"])
         return idx, val, scores
 
     @torch.no_grad()
@@ -181,7 +198,8 @@ class IdentificationModule(torch.nn.Module):
         up = self.camera_up(fmaps)
         idx, val, scores = self.score_tokens(toks, rays_ori, rays_dir, rays_rgb, rays_to_output, want_scores, workspace,
                                              images_in_flight)
-        return dict(idx=idx, values=val, scores=scores, camera_up_dir=up, n_tokens=[int(t.shape[0]) for t in toks], tokens=toks)
+        tl = list(toks) if torch.is_tensor(toks) else toks
+        return dict(idx=idx, values=val, scores=scores, camera_up_dir=up, n_tokens=[int(t.shape[0]) for t in tl], tokens=tl)
 
     @torch.no_grad()
     def test_image(self, img: torch.Tensor, mask: torch.Tensor, rays_ori: torch.Tensor, rays_dir: torch.Tensor,

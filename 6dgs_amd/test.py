@@ -61,6 +61,20 @@ def prepare_image_device(img_u8: torch.Tensor):
     return obs, mask
 
 
+def prepare_images_device(images):
+    """List of uint8 device images -> (fp32 images, masks) with mask None for RGB (all-ones mask, test.py:80-83) and the
+    whole batch converted in one go when the images share a shape."""
+    if len(images) > 1 and all(im.shape == images[0].shape and im.shape[-1] == 3 for im in images):
+        obs = _u8_lut(images[0].device)[torch.stack(list(images)).long()]
+        return list(obs), [None] * len(images)
+    out_i, out_m = [], []
+    for im in images:
+        o, m = prepare_image_device(im)
+        out_i.append(o)
+        out_m.append(m if im.shape[-1] == 4 else None)
+    return out_i, out_m
+
+
 @torch.no_grad()
 def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
                    images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False):
@@ -69,8 +83,8 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
     `tokens` / `up` inject the image-side boundary inputs instead.  Everything is enqueued on the current
     stream; nothing syncs until the caller reads the returned device tensors."""
     if tokens is None:
-        prepared = [prepare_image_device(im) for im in images]
-        tokens, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] for p in prepared])
+        imgs_f, masks = prepare_images_device(images)
+        tokens, fmaps = id_module.image_tokens(imgs_f, masks)
         up = id_module.camera_up(fmaps)
     idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
                                                   workspace=workspace, images_in_flight=images_in_flight, profile=profile)
@@ -131,7 +145,8 @@ def test_pose_estimation(
             up = up_override[b0:b0 + nb].to(dev)
         else:
             prepared = [prepare_image(c.image, dev) for c in cams]
-            toks, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] for p in prepared])
+            has_alpha = [np.asarray(c.image).shape[-1] == 4 for c in cams]
+            toks, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] if a else None for p, a in zip(prepared, has_alpha)])
             up = id_module.camera_up(fmaps)
         idx, weights, pred_scores = id_module.score_tokens(toks, rays_ori, rays_dirs, rays_rgb, k, want_scores=loss_fn is not None)
         avg_score = [-1.0] * nb
@@ -139,7 +154,7 @@ def test_pose_estimation(
         if loss_fn is not None:  # test.py:108-142: evaluate the GROUND-TRUTH top-k instead of the prediction
             new_idx, new_w = [], []
             for i in range(nb):
-                s_i, target_scores = loss_fn(pred_scores[i], gt[i], Ks[i].to(dev), rays_ori, rays_dirs, toks[i].shape[0],
+                s_i, target_scores = loss_fn(pred_scores[i], gt[i], Ks[i].to(dev), rays_ori, rays_dirs, int(toks[i].shape[0]),
                                              id_module.backbone_wrapper.backbone_wh, model_up=up[i])
                 avg_score[i] = s_i.item()
                 target_idx, _ = ops.topk(weights[i], k)

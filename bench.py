@@ -96,7 +96,9 @@ def main():
     torch.cuda.synchronize()
     t_keys = time.time() - t0
     k_ms, k_fl, _, _ = kprof.collect()
-    ws = torch.empty(ops.score_topk_workspace_bytes(R, min(args.in_flight, args.batch), 100), dtype=torch.uint8, device=dev)
+    # images whose [256, R] logits are resident at once: --in-flight, or the whole batch when that fits in 48 GB
+    inflight = args.batch if ops.score_topk_workspace_bytes(R, args.batch, 100) <= 48 * 2**30 else min(args.in_flight, args.batch)
+    ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100), dtype=torch.uint8, device=dev)
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------
