@@ -792,7 +792,8 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
       {
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
-        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * SIXDGS_D * 4.0 + tok * 4.0));
+        // operand bytes per ray: 1536 B fp32 key, or 2304 B of bf16 planes on the DMA-fed path
+        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * (use_v2 ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
         if (use_v2) {
           // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
           hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,

@@ -20,7 +20,7 @@ def main():
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     lines = ["| kernel | calls | total ms | avg ms | % of GPU kernel time |", "|---|---:|---:|---:|---:|"]
     for name, calls, tot, avg, pct in rows[:40]:
-        lines.append(f"| `{short(name)}` | {calls} | {tot / 1e6:.3f} | {avg / 1e6:.4f} | {pct:.2f} |")
+        lines.append(f"| `{short(name)}` | {calls} | {tot / 1e3:.3f} | {avg / 1e3:.4f} | {pct:.2f} |")   # rocpd durations are in us
     geo = ["", "| kernel | grid | workgroup | VGPR | AGPR | SGPR | static LDS B | scratch B |", "|---|---|---|---:|---:|---:|---:|---:|"]
     seen = set()
     for r in cur.execute("select name, grid_x, grid_y, grid_z, workgroup_x, workgroup_y, workgroup_z, vgpr_count, accum_vgpr_count, "
