@@ -20,7 +20,7 @@ import torch.distributed as dist
 _SCENE_FIELDS = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from RANK / WORLD_SIZE / LOCAL_RANK; initialises the process group when
     WORLD_SIZE > 1 (rendezvous through MASTER_ADDR / MASTER_PORT, 127.0.0.1 on one node)."""
     rank = int(os.environ.get("RANK", "0"))
@@ -31,7 +31,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local

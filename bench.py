@@ -62,7 +62,11 @@ def main():
     ops = importlib.import_module("6dgs_amd.ops")
     tp = importlib.import_module("6dgs_amd.test")
 
-    rank, world, local = dd.init_from_env()
+    # test hooks (tests/ and CI only): run the N > 1 code path with several ranks on one device over gloo
+    forced_dev = os.environ.get("SIXDGS_BENCH_FORCE_DEVICE")
+    rank, world, local = dd.init_from_env(os.environ.get("SIXDGS_BENCH_BACKEND"), set_device=forced_dev is None)
+    if forced_dev is not None:
+        local = int(forced_dev)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
