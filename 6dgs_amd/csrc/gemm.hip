@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(256, 2) k_linear(GemmOperands g, const float* 
 }
 
 int resolve_mma(int mode) {
-  if (mode == SIXDGS_MMA_F32 || mode == SIXDGS_MMA_BF16X6) return mode;
-  return SIXDGS_MMA_BF16X6;  // SIXDGS_MMA_DEFAULT
+  if (mode == SIXDGS_MMA_F32) return mode;
+  return SIXDGS_MMA_BF16X6;  // DEFAULT, BF16X6 and F16X3 (the dense layers have no scaled-fp16 variant yet)
 }
 
 int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, hipStream_t s, int mma) {
@@ -232,18 +232,21 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
                     float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, nullptr, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
+  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, nullptr, nullptr, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
-                       float* key, void* key_planes, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
-                       int mma_mode) {
+                       float* key, void* key_planes, float* key_inv_scale, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
+                       sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
+  const bool f16 = key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT);
+  SDG_CHECK_ARG(!f16 || key_inv_scale);
   const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float)));
   if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;
   const int64_t chunk = chunk_cap < r ? (chunk_cap >= 128 ? chunk_cap / 128 * 128 : chunk_cap) : r;
+  if (f16 && chunk < r && (chunk % 128) != 0) return SIXDGS_E_WORKSPACE;   // scale tiles must not straddle chunks
   hipStream_t s = sdg_stream(stream);
   float* x = (float*)ws;
   float* h1 = x + chunk * SIXDGS_RAY_IN_PAD;
@@ -270,7 +273,9 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
       float* kdst = key ? key + r0 * SIXDGS_D : h1;
       GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
       if ((st = launch_linear(g5, w->bk, false, kdst, SIXDGS_D, s, mma_mode))) return st;
-      if (key_planes && (st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream))) return st;
+      if (f16) st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
+      else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
+      if (st) return st;
     }
   }
   return 0;

@@ -437,6 +437,309 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 1, fp16x3 variant (SIXDGS_MMA_F16X3): TWO scaled fp16 planes per operand, THREE cross terms.
+// x * 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h): fp16 carries 11 significant bits, so h + l reproduces
+// x to 2^-23 and l*h + h*l + h*h to ~2^-22 per product (every fp16 x fp16 product is exact in fp32).  The power-of-two
+// scale (one per key set, one per image on the q side; chosen so that max|x| 2^s is in [2^13, 2^14]) keeps h and l in
+// fp16's normal range for everything within 2^-17 of the largest value and is undone exactly by the epilogue constant.
+// Measured (tools/probe_f16x3.py, K = 384): 1.0e-7 * sum|a||b|, below both the fp32 MFMA chain (1.6e-7) and bf16x6.
+// Half the MFMA instructions of bf16x6 and 2/3 of its operand bytes (1536 B per row, the size of fp32).
+// Same structure as k_logits_v2; geometry: 4 regions (A planes 0,1; B planes 0,1) of 128 rows x 64 B per 32-k slab =
+// 32 KiB per stage, 4-stage ring (128 KiB) -> the DMA of slab s+3 is issued after the barrier of slab s; 8 DMA pieces,
+// 16 ds_read_b128 and 24 MFMA per slab and wave.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kNsF = 4;                   // ring stages
+constexpr int kStageF = 4 * kRegion;      // A h,l ; B h,l
+constexpr int kRingF = kNsF * kStageF;
+constexpr int kRowF = 12 * 2 * 64;        // 1536 B of planes per operand row
+constexpr int kSlabF = 128;               // bytes per row and slab
+
+struct LogitsF16Args {
+  const char* qp;        // [B][256][1536 B]
+  const int* n_tok;
+  const char* kp;        // [R][1536 B]
+  const float* qinv;     // [B][2] reciprocal power-of-two scale of each 128-token half, indexed like qp
+  const float* kinv;     // [ceil(R/128)] reciprocal power-of-two scale of each 128-ray tile
+  float* logits;
+  float* partial;
+  int64_t r, ldl;
+  int tiles_per_group, n_tiles, n_groups, b0;
+};
+
+__device__ __forceinline__ f16x8 lds_read_frag_h(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+__global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
+  __shared__ __attribute__((aligned(1024))) char lds[kRingF + 2 * 128 * 8 + 4 * 64 * 4];
+  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds + kRingF);
+  float* rowmax = reinterpret_cast<float*>(lds + kRingF + 2 * 128 * 8);   // [4 waves][64 rows]
+  const int bl = blockIdx.y;
+  const int b = A.b0 + bl;
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = (int)(w >> 1), m_tile = (int)(w & 1u);
+  const int M = A.n_tok[b];
+  const float cq = A.qinv[2 * b + m_tile];
+  const int row0 = m_tile * 128;
+  float* pout = A.partial + (((int64_t)bl * A.n_groups + grp) * kT + row0) * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  float m_run = -INFINITY, s_run = 0.f;
+  const int t_begin = grp * A.tiles_per_group;
+  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+  if (row0 < M && t_begin < t_end) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    // ---- DMA pieces: piece i of this wave is 1-KiB block 4 (i & 1) + wave of region (i >> 1): A h, A l, B h, B l ------
+    unsigned offA[4], offB[4];
+    int rowB[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sub = 4 * (i & 1) + wave;
+      const int chunk = sub * 64 + lane;
+      const int row = chunk >> 2, pos = chunk & 3;
+      const int c = pos ^ ((row >> 2) & 3);
+      const unsigned inrow = (unsigned)(((i >> 1) & 1) * 64 + c * 16);
+      if (i < 4) {
+        offA[i] = (unsigned)min(row0 + row, M - 1) * kRowF + inrow;
+      } else {
+        rowB[i - 4] = row;
+        offB[i - 4] = inrow;
+      }
+    }
+    const char* qbase = A.qp + (int64_t)b * kT * kRowF;
+    // one DMA piece (i = 0..3 key pieces first: HBM; i = 4..7 q pieces: L2) of slab s into ring stage `stage`
+    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {
+      char* sbase = lds + stage * kStageF + wave * 1024;
+      if (i < 4) {
+        const unsigned ob = (unsigned)min(rowB[i], lim) * kRowF + offB[i] + (unsigned)(s * kSlabF);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (2 + (i >> 1)) * kRegion + (i & 1) * 4096), 16, 0, 0);
+      } else {
+        const int k = i - 4;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[k] + (unsigned)(s * kSlabF))),
+                                         (lds_ptr_t)(sbase + (k >> 1) * kRegion + (k & 1) * 4096), 16, 0, 0);
+      }
+    };
+    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) issue_piece(kbase, lim, s, stage, i);
+    };
+    auto tile_lim = [&](int tile) {
+      const int64_t left = A.r - (int64_t)tile * kBN - 1;
+      return left < 127 ? (int)left : 127;
+    };
+    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + (lane >> 5);
+        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
+        fb[t][ks] = lds0 + 2 * kRegion + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+      }
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl;
+    const unsigned lane_elem = (unsigned)(4 * (lane >> 5)) * (unsigned)A.ldl + (unsigned)(wn * 64 + (lane & 31));
+    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowF;
+    int lim_cur = tile_lim(t_begin);
+
+    f16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    auto wait_lds = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // slabs still in flight BEHIND the awaited one: 2 in steady state (ring of 4), fewer at the end of the run
+    auto wait_slab = [&](int ahead) {
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    // prologue of the run: slabs 0..2 of the first tile, B(0), slab 3, fragments (0, ks0).  (A tile has 12 >= 4 slabs.)
+    issue(kcur, lim_cur, 0, 0);
+    issue(kcur, lim_cur, 1, 1);
+    issue(kcur, lim_cur, 2, 2);
+    wait_slab(2);
+    issue(kcur, lim_cur, 3, 3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f0a[t][p] = lds_read_frag_h(fa[t][0] + p * kRegion);
+        f0b[t][p] = lds_read_frag_h(fb[t][0] + p * kRegion);
+      }
+    wait_lds();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int64_t col0 = (int64_t)tile * kBN;
+      const bool has_next = tile + 1 < t_end;
+      const char* knext = kcur + (int64_t)kBN * kRowF;
+      const int lim_next = has_next ? tile_lim(tile + 1) : 0;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+      // 12 MFMAs on (xa, xb): l*h, h*l, h*h for the 4 accumulators; side work rides in the MFMA slots: the 8 fragment
+      // reads of the next k-step (slots 0..7) and optionally the 8 DMA pieces of a later slab (slots 0..7).
+      auto mfma_step = [&](f16x8 (&xa)[2][2], f16x8 (&xb)[2][2], f16x8 (&na)[2][2], f16x8 (&nb)[2][2], const bool do_read,
+                           const int rstage, const int rks, const bool do_dma, const char* dkb, const int dlim, const int ds,
+                           const int dstage) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+        const unsigned st = (unsigned)(rstage * kStageF);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int z = 0; z < 4; ++z) {
+            const int slot = q * 4 + z;        // 0..11
+            const int tm = z >> 1, tn = z & 1;
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[tm][PA[q]], xb[tn][PB[q]], acc[tm][tn], 0, 0, 0);
+            if (do_read && slot < 8) {
+              const int op = slot >> 2, t = (slot >> 1) & 1, pp = slot & 1;
+              if (op == 0) na[t][pp] = lds_read_frag_h(fa[t][rks] + st + pp * kRegion);
+              else nb[t][pp] = lds_read_frag_h(fb[t][rks] + st + pp * kRegion);
+            }
+            if (do_dma && slot < 8) issue_piece(dkb, dlim, ds, dstage, slot);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+
+      for (int s0 = 0; s0 < 12; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {     // slab sl = s0 + u sits in ring stage u (12 slabs per tile = 0 mod 4)
+          const int sl = s0 + u;
+          mfma_step(f0a, f0b, f1a, f1b, true, u, 1, false, nullptr, 0, 0, 0);
+          wait_lds();
+          const bool more = sl < 11 || has_next;
+          if (more) {
+            // slabs issued beyond slab sl+1 at this point: sl+2, sl+3 (when they exist)
+            const int last = has_next ? 11 + 4 : 11;          // last slab index (in this tile's numbering) ever issued
+            const int ahead = min(2, last - (sl + 1));
+            wait_slab(ahead);
+          }
+          const bool dma_same = more && (sl + 4 < 12);
+          const bool dma_next = more && (sl + 4 >= 12) && has_next;
+          if (dma_same) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 4, 0, true, kcur, lim_cur, sl + 4, u);
+          else if (dma_next) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 4, 0, true, knext, lim_next, sl + 4 - 12, u);
+          else mfma_step(f1a, f1b, f0a, f0b, more, (u + 1) % 4, 0, false, nullptr, 0, 0, 0);
+          wait_lds();
+        }
+      }
+
+      // ---- epilogue (as k_logits_v2; the constant undoes both power-of-two operand scales, exactly, and applies 1/sqrt 384)
+      const float cf = (cq * A.kinv[tile]) * kInvSqrtD;
+      const bool v0 = col0 + acc_col(wn, 0, lane) < A.r, v1 = col0 + acc_col(wn, 1, lane) < A.r;
+      float mx[32];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* rowp = lg + (int64_t)(row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2)) * A.ldl + col0;
+          const float l0 = acc[tm][0][r] * cf, l1 = acc[tm][1][r] * cf;
+          acc[tm][0][r] = l0;
+          acc[tm][1][r] = l1;
+          rowp[lane_elem] = l0;
+          rowp[lane_elem + 32u] = l1;
+          mx[tm * 16 + r] = fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY);
+        }
+      const float my_max = transpose_reduce32<true>(mx, lane);
+      float* rmx = rowmax + wave * 64 + (lane >> 5) * 32;
+      rmx[lane & 31] = my_max;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float sm[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float m = rmx[j];
+        const int tm = j >> 4, r = j & 15;
+        const float e0 = v0 ? __expf(acc[tm][0][r] - m) : 0.f, e1 = v1 ? __expf(acc[tm][1][r] - m) : 0.f;
+        sm[j] = (m > -INFINITY) ? e0 + e1 : 0.f;
+      }
+      const float my_sum = transpose_reduce32<false>(sm, lane);
+      {
+        const int j = lane & 31;
+        const int lr = acc_row(wm, j >> 4, j & 15, lane);
+        part[wn][lr][0] = my_max;
+        part[wn][lr][1] = my_sum;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < 128) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float mt = part[h][tid][0], st2 = part[h][tid][1];
+          if (mt > -INFINITY) {
+            const float mn = fmaxf(m_run, mt);
+            s_run = s_run * __expf(m_run - mn) + st2 * __expf(mt - mn);
+            m_run = mn;
+          }
+        }
+      }
+      kcur = knext;
+      lim_cur = lim_next;
+    }
+  }
+  if (tid < 128) {
+    pout[2 * tid] = m_run;
+    pout[2 * tid + 1] = s_run;
+  }
+}
+
+// fp32 rows [rows][384] (row stride ld) -> fp16 planes [row][12][2][32] of x * 2^s, one power-of-two scale per 128-row
+// tile chosen so that the tile's largest magnitude lands in [2^13, 2^14); inv_scale[tile] = 2^-s.  One block per tile; the
+// second sweep over the tile's 192 KiB hits L2.
+__global__ void __launch_bounds__(256) k_split_tiles_f16(const float* __restrict__ src, int64_t rows, int64_t ld, char* __restrict__ dst,
+                                                         float* __restrict__ inv_scale) {
+  __shared__ float wmax[4];
+  const int64_t row0 = (int64_t)blockIdx.x * 128;
+  const int n = (int)min((int64_t)128, rows - row0);
+  const float* base = src + row0 * ld;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n * 96; i += 256) {
+    const int row = i / 96;
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + (i - row * 96) * 4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));   // NaN operands are skipped by fmaxf
+  }
+  m = sdg_wave_max(m);
+  if (sdg_lane() == 0) wmax[sdg_wave()] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int sh = 0;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(14 - e) in [2^13, 2^14)
+    sh = 14 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  }
+  const float sc = ldexpf(1.f, sh);
+  if (threadIdx.x == 0) inv_scale[blockIdx.x] = ldexpf(1.f, -sh);
+  for (int i = threadIdx.x; i < n * 48; i += 256) {
+    const int row = i / 48, k8 = i - row * 48;
+    const float* sp = base + (int64_t)row * ld + k8 * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(sp);
+    const float4 hi = *reinterpret_cast<const float4*>(sp + 4);
+    const float x[8] = {lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc};
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 hh = (_Float16)x[e];
+      h[e] = hh;
+      l[e] = (_Float16)(x[e] - (float)hh);
+    }
+    char* d = dst + (row0 + row) * kRowF + (k8 >> 2) * kSlabF + (k8 & 3) * 16;
+    *reinterpret_cast<f16x8*>(d) = h;
+    *reinterpret_cast<f16x8*>(d + 64) = l;
+  }
+}
+
 // fp32 rows [rows][384] (row stride ld) -> bf16 planes [rows][12][3][32]; 8 consecutive k per thread
 __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ src, int64_t rows, int64_t ld, char* __restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -718,7 +1021,7 @@ ScorePlan score_plan(int64_t r, int batch, int topk) {
   p.per_image_partial = sdg_align((size_t)p.n_groups * kT * 2 * sizeof(float));
   p.per_image_stats = sdg_align((size_t)kT * 2 * sizeof(float));
   p.per_image_scores = sdg_align((size_t)p.ldl * sizeof(float));
-  p.per_image_qplanes = sdg_align((size_t)kT * kRowBytes, 1024);
+  p.per_image_qplanes = sdg_align((size_t)kT * kRowBytes, 1024) + 256;   // + absmax / scale / epilogue constant of the image
   p.topk_bytes = topk_plan(r, batch, topk).bytes;
   return p;
 }
@@ -746,6 +1049,18 @@ size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
 
 size_t sixdgs_key_planes_bytes(int64_t r) { return (size_t)(r > 0 ? r : 0) * kRowBytes; }
 
+size_t sixdgs_key_planes_f16_bytes(int64_t r) { return (size_t)(r > 0 ? r : 0) * kRowF; }
+
+int sixdgs_split_planes_f16(const float* src, int64_t rows, int64_t ld, void* planes, float* d_inv_scale, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(rows >= 0 && ld >= SIXDGS_D && (ld % 4) == 0);
+  if (rows == 0) return 0;
+  SDG_CHECK_ARG(src && planes && d_inv_scale && ((uintptr_t)src % 16) == 0 && ((uintptr_t)planes % 16) == 0);
+  hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)sdg_cdiv(rows, 128)), dim3(256), 0, sdg_stream(stream), src, rows, ld,
+                     (char*)planes, d_inv_scale);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
 int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(rows >= 0 && ld >= SIXDGS_D && (ld % 4) == 0);
   if (rows == 0) return 0;
@@ -757,10 +1072,13 @@ int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes
 }
 
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
-                         const void* key_planes, int64_t r, int topk, float* scores, int64_t* idx, float* val, float* row_stats,
-                         void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
+                         const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* scores, int64_t* idx,
+                         float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
+                         int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
+  const bool use_f16 = key_planes != nullptr && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT);
+  SDG_CHECK_ARG(!use_f16 || d_key_scale != nullptr);
   const bool use_v2 = key_planes != nullptr && mma_mode != SIXDGS_MMA_F32;
   SDG_CHECK_ARG(q && d_n_tok && (key || use_v2 || r == 0) && idx && val && ws);
   SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
@@ -793,8 +1111,17 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
         // operand bytes per ray: 1536 B fp32 key, or 2304 B of bf16 planes on the DMA-fed path
-        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (nb * (use_v2 ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
-        if (use_v2) {
+        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r,
+                              (double)r * (nb * ((use_v2 && !use_f16) ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
+        if (use_f16) {
+          // scaled fp16 planes of q (one power-of-two scale per 128-token half), then the fp16x3 kernel
+          float* qinv = (float*)(qplanes + (size_t)bg * (p.per_image_qplanes - 256));
+          hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q + (int64_t)b0 * kT * SIXDGS_D,
+                             (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes, qinv);
+          LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)key_planes, qinv - 2 * b0, d_key_scale, logits,
+                             partial, r, A.ldl, p.tiles_per_group, p.n_tiles, p.n_groups, b0};
+          hipLaunchKernelGGL(k_logits_f16, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, V);
+        } else if (use_v2) {
           // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
           hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,
                              q + (int64_t)b0 * kT * SIXDGS_D, (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes);
@@ -845,8 +1172,8 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
 
 int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,
                       int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, nullptr, r, topk, scores, idx, val, row_stats, ws, ws_bytes, stream,
-                              nullptr, SIXDGS_MMA_DEFAULT);
+  return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, nullptr, nullptr, r, topk, scores, idx, val, row_stats, ws, ws_bytes,
+                              stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches) {

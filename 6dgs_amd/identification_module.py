@@ -109,17 +109,21 @@ class IdentificationModule(torch.nn.Module):
     def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None):
         w = self.packed_weights(rays_ori.device)
         ident = (rays_ori.data_ptr(), rays_dir.data_ptr(), rays_rgb.data_ptr(), rays_ori.shape[0], rays_ori._version,
-                 rays_dir._version, rays_rgb._version, self._packed_key, ops.get_mma_mode())
+                 rays_dir._version, rays_rgb._version, self._packed_key, ops.effective_mma_mode())
         if self._key_cache is None or self._key_cache_id != ident:
             r = rays_ori.shape[0]
-            planes_mode = ops.get_mma_mode() != ops.MMA_F32
+            mode = ops.effective_mma_mode()
+            planes_mode = mode != ops.MMA_F32
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
+            scale = None
             if planes_mode:
                 _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True)
+                if mode == ops.MMA_F16X3:
+                    planes, scale = planes
             else:
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
                 planes = None
-            self._key_cache, self._key_cache_id = {"key": key, "planes": planes}, ident
+            self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale}, ident
         return self._key_cache
 
     def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
@@ -187,7 +191,7 @@ class IdentificationModule(torch.nn.Module):
         q = ops.q_proj(tokens, n_tok, w)
         idx, val, scores, _ = ops.score_topk(q, n_tok, kc["key"], rays_to_output, want_scores=want_scores, workspace=workspace,
                                              images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
-                                             key_planes=kc["planes"])
+                                             key_planes=kc["planes"], key_scale=kc["scale"])
         return idx, val, scores
 
     @torch.no_grad()

@@ -12,19 +12,25 @@ from . import _lib
 from ._lib import Profile, ScorerWeights, check
 
 D = 384
-MMA_DEFAULT, MMA_F32, MMA_BF16X6 = -1, 0, 1
+MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3 = -1, 0, 1, 2
+MMA_LIBRARY_DEFAULT = MMA_F16X3
 _mma_mode = MMA_DEFAULT
 
 
 def set_mma_mode(mode: int):
     """Select how the fp32 contractions run on the matrix cores (see SIXDGS_MMA_* in include/sixdgs.h)."""
     global _mma_mode
-    assert mode in (MMA_DEFAULT, MMA_F32, MMA_BF16X6)
+    assert mode in (MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3)
     _mma_mode = mode
 
 
 def get_mma_mode() -> int:
     return _mma_mode
+
+
+def effective_mma_mode() -> int:
+    """The mode MMA_DEFAULT resolves to inside the library."""
+    return MMA_LIBRARY_DEFAULT if _mma_mode == MMA_DEFAULT else _mma_mode
 
 RAY_IN_PAD = 144
 TOK_IN = 398
@@ -265,9 +271,20 @@ def split_planes(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_planes_f16(x: torch.Tensor):
+    """fp32 [rows,384] -> (scaled fp16 planes as uint8 [rows,1536], reciprocal power-of-two scale of every 128-row tile)."""
+    x = _f32(x)
+    _need_gpu(x)
+    out = torch.empty(x.shape[0], 1536, dtype=torch.uint8, device=x.device)
+    scale = torch.empty((x.shape[0] + 127) // 128, device=x.device)
+    check(_lib.load().sixdgs_split_planes_f16(_p(x), x.shape[0], x.stride(0), _p(out), _p(scale), _stream()), "split_planes_f16")
+    return out, scale
+
+
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
              workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False):
-    """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes uint8 [R,2304])."""
+    """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes) where planes is uint8 [R,2304]
+    (bf16 planes) or, in MMA_F16X3 mode, the pair (uint8 [R,1536] scaled fp16 planes, inv_scale [ceil(R/128)])."""
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
     lib = _lib.load()
@@ -275,12 +292,17 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     dev = ori.device
     feat = torch.empty(r, D, device=dev) if want_feat else None
     key = torch.empty(r, D, device=dev) if want_key else None
-    planes = torch.empty(r, 2304, dtype=torch.uint8, device=dev) if want_planes else None
+    mode = effective_mma_mode()
+    f16 = want_planes and mode == MMA_F16X3
+    planes = torch.empty(r, 1536 if f16 else 2304, dtype=torch.uint8, device=dev) if want_planes else None
+    inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(ws), ws.numel(),
-                                 _stream(), profile.ref if profile is not None else None, _mma_mode), "ray_keys")
-    return (feat, key, planes) if want_planes else (feat, key)
+    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(ws), ws.numel(),
+                                 _stream(), profile.ref if profile is not None else None, mode), "ray_keys")
+    if want_planes:
+        return feat, key, ((planes, inv) if f16 else planes)
+    return feat, key
 
 
 def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -311,8 +333,10 @@ def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100) -> int:
 
 def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], topk: int = 100, want_scores: bool = True,
                want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
-               profile: Optional["KernelProfile"] = None, n_tok_host=None, key_planes: Optional[torch.Tensor] = None):
-    """key: fp32 [R,384] and/or key_planes: uint8 [R,2304] (bf16 planes; selects the DMA-fed kernel unless MMA_F32)."""
+               profile: Optional["KernelProfile"] = None, n_tok_host=None, key_planes: Optional[torch.Tensor] = None,
+               key_scale: Optional[torch.Tensor] = None):
+    """key: fp32 [R,384] and/or key_planes: uint8 [R,2304] bf16 planes (BF16X6) or [R,1536] scaled fp16 planes + key_scale
+    (F16X3); planes select the DMA-fed kernels unless the mode is MMA_F32."""
     q = _f32(q)
     key = _f32(key) if key is not None else None
     _need_gpu(q, key, n_tok, key_planes)
@@ -329,7 +353,12 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
     h_n = None
     if profile is not None and n_tok_host is not None:
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
-    check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
+    mode = effective_mma_mode()
+    if key_planes is not None and mode != MMA_F32:
+        want = 1536 if mode == MMA_F16X3 else 2304
+        if key_planes.shape[1] != want or (mode == MMA_F16X3 and key_scale is None):
+            raise RuntimeError("6dgs_amd: key planes are not in the format of the active MMA mode")
+    check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
                                    _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,
                                    _mma_mode), "score_topk")
     return idx, val, scores, stats

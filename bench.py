@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--mode", choices=["full", "reference"], default="full",
                     help="full: every Gaussian, iso-cell emitter (headline); reference: 1000-ellipsoid quadricell subsample")
     ap.add_argument("--image-size", type=int, default=800)
+    ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f32"], default="default",
+                    help="matrix-core scheme of the logits kernel (default = the library's default mode)")
     ap.add_argument("--in-flight", type=int, default=2, help="images whose [256,R] logits are resident at once")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
@@ -61,6 +63,7 @@ def main():
     dd = importlib.import_module("6dgs_amd.distributed")
     ops = importlib.import_module("6dgs_amd.ops")
     tp = importlib.import_module("6dgs_amd.test")
+    ops.set_mma_mode({"default": ops.MMA_DEFAULT, "bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[args.mma])
 
     # test hooks (tests/ and CI only): run the N > 1 code path with several ranks on one device over gloo
     forced_dev = os.environ.get("SIXDGS_BENCH_FORCE_DEVICE")
@@ -162,16 +165,21 @@ def main():
             except Exception:
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0
-        b6 = ops.get_mma_mode() != ops.MMA_F32
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if b6 else PEAK_F32_MFMA_TFLOPS
+        mode = ops.effective_mma_mode()
+        terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3}[mode]
+        peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_BF16_MFMA_TFLOPS / terms
+        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3"}[mode]
         out["roofline"] = {
-            "kernel": ("k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16 "
-                       "(fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once") if b6 else
-                      "k_logits<f32>: q.K^T on v_mfma_f32_32x32x2_f32, online row stats, logits stored once",
+            "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
+                                       "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
+                       ops.MMA_F16X3: "k_logits_f16: q.K^T with fp32 operands scaled by a power of two and split into 2 fp16 planes, 3 cross "
+                                      "terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
+                       ops.MMA_F32: "k_logits<f32>: q.K^T on v_mfma_f32_32x32x2_f32, online row stats, logits stored once"}[mode],
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),
-            "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 MFMA terms per fp32 product; achieved = algorithmic 2*T*384 FLOP per "
-                           "ray and image / HIP-event time (executed bf16 MFMA rate = 6x achieved)") if b6 else "157.3 TFLOP/s dense fp32 MFMA",
+            "peak_basis": "157.3 TFLOP/s dense fp32 MFMA" if mode == ops.MMA_F32 else
+                          ("2500 TFLOP/s dense 16-bit MFMA / %d MFMA terms per fp32 product; achieved = algorithmic 2*T*384 FLOP per "
+                           "ray and image / HIP-event time (executed 16-bit MFMA rate = %dx achieved)" % (terms, terms)),
             "achieved_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "launches": l_n, "avg_launch_ms": round(l_ms / max(l_n, 1), 4),
             "algorithmic_flop_per_launch": l_fl / max(l_n, 1), "algorithmic_bytes_per_launch": l_by / max(l_n, 1),

@@ -48,10 +48,15 @@ typedef void* sixdgs_stream_t;
  *   F32     v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s peak;
  *   BF16X6  each fp32 operand split into 3 bf16 planes, the 6 leading cross terms accumulated in fp32 by
  *           v_mfma_f32_32x32x16_bf16: per-product error <= 2^-26 (below fp32 rounding), 2.67x less
- *           matrix-pipe time.  DEFAULT = BF16X6. */
+ *           matrix-pipe time. */
 #define SIXDGS_MMA_DEFAULT (-1)
 #define SIXDGS_MMA_F32 0
 #define SIXDGS_MMA_BF16X6 1
+/*   F16X3   (scorer logits only) every 128-row tile of an operand scaled by a power of two and split into 2 fp16 planes,
+ *           3 cross terms on v_mfma_f32_32x32x16_f16: measured error 1.0e-7 sum|a||b| (below the fp32 chain), half the
+ *           MFMA work of BF16X6 and fp32-sized operands; the dense layers run BF16X6 in this mode.
+ *   DEFAULT = F16X3 (scorer) + BF16X6 (dense layers). */
+#define SIXDGS_MMA_F16X3 2
 
 /* Optional kernel timing, owned by the caller (the library stays stateless): zero-initialise, pass to
  * the *_ex entry points; each launch of the dominant kernel is bracketed by a pair of HIP events on
@@ -176,12 +181,19 @@ int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_
 /* key_planes (optional, sixdgs_key_planes_bytes(r) bytes): the keys pre-split into three bf16 planes,
  * [R][12 k-slabs][3 planes][32] -- the operand format of the DMA-fed bf16x6 scorer kernel.  With key == NULL only
  * the planes are kept (2304 B per ray instead of 1536 B fp32). */
+/* mma_mode == SIXDGS_MMA_F16X3: key_planes are the scaled fp16 planes (sixdgs_key_planes_f16_bytes(r) bytes, 1536 B per
+ * ray) and key_inv_scale[ceil(r/128)] (device, required) receives the per-tile reciprocal scales. */
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
-                       float* feat, float* key, void* key_planes, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
-                       sixdgs_profile* prof, int mma_mode);
+                       float* feat, float* key, void* key_planes, float* key_inv_scale, void* ws, size_t ws_bytes,
+                       sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
 size_t sixdgs_key_planes_bytes(int64_t r);
 /* fp32 rows [rows][384] (row stride ld floats) -> bf16 planes [rows][12][3][32] (x = h + m + l exactly) */
 int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream);
+/* fp32 rows -> scaled fp16 planes [rows][12][2][32] (1536 B per row) for SIXDGS_MMA_F16X3: every 128-row tile is scaled
+ * by the power of two that puts its largest magnitude in [2^13, 2^14); d_inv_scale[ceil(rows/128)] (device) receives the
+ * reciprocal scales.  Splitting a row range in chunks is valid when every chunk starts at a multiple of 128 rows. */
+size_t sixdgs_key_planes_f16_bytes(int64_t r);
+int sixdgs_split_planes_f16(const float* src, int64_t rows, int64_t ld, void* planes, float* d_inv_scale, sixdgs_stream_t stream);
 
 /* generic fp32 MFMA GEMM used by the above: y[M,N] = act(x[M,K] . w[N,K]^T + b), K % 16 == 0,
  * N % 128 == 0, ldx/ldw/ldy in floats and multiples of 4. */
@@ -210,11 +222,13 @@ int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, in
                       float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,
                       size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing each launch of the logits kernel (2*T*384 algorithmic FLOP per ray and image) into `prof` */
-/* key_planes != NULL (and mma_mode != F32) selects the DMA-fed bf16x6 kernel; `key` (fp32) may then be NULL. */
+/* key_planes != NULL (and mma_mode != F32) selects a DMA-fed kernel; `key` (fp32) may then be NULL.  The planes must be in
+ * the format of the mode: bf16 planes (sixdgs_split_planes) for BF16X6 / DEFAULT, scaled fp16 planes + d_key_scale (the
+ * d_inv_scale of sixdgs_split_planes_f16 / sixdgs_ray_keys_ex) for F16X3. */
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy, for the FLOP count*/,
-                         int batch, const float* key, const void* key_planes, int64_t r, int topk, float* scores,
-                         int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
-                         sixdgs_profile* prof, int mma_mode);
+                         int batch, const float* key, const void* key_planes, const float* d_key_scale, int64_t r, int topk,
+                         float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,
+                         sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

@@ -195,10 +195,10 @@ def test_a10_sh_colour(ops, golden, deg):
 # ------------------------------------------------------------------------------------------------
 # scorer
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["bf16x6", "f32"])
+@pytest.fixture(scope="module", params=["bf16x6", "f16x3", "f32"])
 def scorer(request, ops, oracle, golden, syn):
-    """Runs every scorer test under both matrix-core modes (SIXDGS_MMA_BF16X6 is the default)."""
-    ops.set_mma_mode(ops.MMA_BF16X6 if request.param == "bf16x6" else ops.MMA_F32)
+    """Runs every scorer test under all three matrix-core modes."""
+    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[request.param])
     request.addfinalizer(lambda: ops.set_mma_mode(ops.MMA_DEFAULT))
     g = golden("g5_scorer")
     sd = syn.make_scorer_state_dict(0)
@@ -206,9 +206,17 @@ def scorer(request, ops, oracle, golden, syn):
     w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
     feat, key, planes = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True, want_planes=True)
     ofeat, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
-    # bf16x6 mode scores through the DMA-fed kernel on the pre-split planes; f32 mode on the fp32 keys
+    # bf16x6 / f16x3 modes score through the DMA-fed kernels on pre-split planes; f32 mode on the fp32 keys
+    kscale = None
+    if request.param == "f16x3":
+        planes, kscale = planes
+        # the planes written chunk by chunk behind k_proj are those of a single split pass over the finished keys
+        p2, s2 = ops.split_planes_f16(key)
+        assert torch.equal(p2, planes) and torch.equal(s2, kscale)
+        _, _, (p3, s3) = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_key=False, want_planes=True, max_chunk=1024)
+        assert torch.equal(p3, planes) and torch.equal(s3, kscale)
     return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey, mode=request.param,
-                planes=planes if request.param == "bf16x6" else None)
+                planes=planes if request.param != "f32" else None, kscale=kscale)
 
 
 def test_a12_ray_encode(ops, oracle, scorer):
@@ -272,7 +280,8 @@ def test_a14_a15_score_topk(ops, oracle, scorer, syn, tag, T, scale):
     oq = oracle.q_proj(tok, scorer["sd"])
     assert rel_err(N(q)[0, :T], oq) < 5e-6
     assert (N(q)[0, T:] == 0).all()
-    idx, val, scores, stats = ops.score_topk(q, n_tok, scorer["key"], 100, want_stats=True, key_planes=scorer["planes"])
+    idx, val, scores, stats = ops.score_topk(q, n_tok, scorer["key"], 100, want_stats=True, key_planes=scorer["planes"],
+                                             key_scale=scorer["kscale"])
     s = N(scores)[0]
     # values: 1e-5 relative against the reference's fp32 result and against the oracle
     assert rel_err(s, g[f"{tag}_scores"]) < 1e-5
@@ -301,13 +310,13 @@ def test_score_topk_batched_and_grouped(ops, scorer, syn):
     toks = [syn.make_tokens(t, 10 + i, 40.0) for i, t in enumerate((256, 137, 1, 200, 0))]
     tokens, n_tok = ops.pad_tokens([G(t) for t in toks], "cuda")
     q = ops.q_proj(tokens, n_tok, scorer["w"])
-    kp = scorer["planes"]
-    idx, val, sc, _ = ops.score_topk(q, n_tok, scorer["key"], 100, key_planes=kp)
-    idx1, val1, sc1, _ = ops.score_topk(q, n_tok, scorer["key"], 100, images_in_flight=1, key_planes=kp)
+    kp, ks = scorer["planes"], scorer["kscale"]
+    idx, val, sc, _ = ops.score_topk(q, n_tok, scorer["key"], 100, key_planes=kp, key_scale=ks)
+    idx1, val1, sc1, _ = ops.score_topk(q, n_tok, scorer["key"], 100, images_in_flight=1, key_planes=kp, key_scale=ks)
     assert torch.equal(idx, idx1) and torch.equal(val, val1) and torch.equal(sc, sc1)
     for i in range(4):
         qi = q[i:i + 1].contiguous()
-        ii, vi, si, _ = ops.score_topk(qi, n_tok[i:i + 1].contiguous(), scorer["key"], 100, key_planes=kp)
+        ii, vi, si, _ = ops.score_topk(qi, n_tok[i:i + 1].contiguous(), scorer["key"], 100, key_planes=kp, key_scale=ks)
         assert torch.equal(ii[0], idx[i]) and torch.equal(si[0], sc[i])
     assert (N(sc)[4] == 0).all()                          # no tokens -> all-zero scores (empty sum)
     assert (N(idx)[4] == np.arange(100)).all()            # all ties -> lowest indices
@@ -327,13 +336,57 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
     tokens, n_tok = ops.pad_tokens([G(tok)], "cuda")
     q = ops.q_proj(tokens, n_tok, scorer["w"])
     res = {}
-    for name, mode, kp in (("f32", ops.MMA_F32, None), ("b6", ops.MMA_BF16X6, None), ("b6dma", ops.MMA_BF16X6, ops.split_planes(key))):
+    p16, s16 = ops.split_planes_f16(key)
+    for name, mode, kp, ks in (("f32", ops.MMA_F32, None, None), ("b6", ops.MMA_BF16X6, None, None),
+                               ("b6dma", ops.MMA_BF16X6, ops.split_planes(key), None), ("f16x3", ops.MMA_F16X3, p16, s16)):
         ops.set_mma_mode(mode)
-        res[name] = ops.score_topk(q, n_tok, key, 100, key_planes=kp)
-    ops.set_mma_mode(ops.MMA_BF16X6 if scorer["mode"] == "bf16x6" else ops.MMA_F32)
-    for name in ("b6", "b6dma"):
+        res[name] = ops.score_topk(q, n_tok, key, 100, key_planes=kp, key_scale=ks)
+    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[scorer["mode"]])
+    # the scaled fp16 planes reproduce the keys to 2^-22 relative to the largest key of each 128-ray tile
+    kn = N(key).astype(np.float64)
+    inv = N(s16).astype(np.float64)
+    assert inv.shape[0] == (kn.shape[0] + 127) // 128 and np.all(np.log2(inv) == np.round(np.log2(inv)))
+    h = p16.cpu().numpy().reshape(-1, 12, 2, 32, 2)
+    rec = (h[..., 0].astype(np.uint16) | (h[..., 1].astype(np.uint16) << 8)).view(np.float16).astype(np.float64).sum(axis=2).reshape(-1, 384)
+    for t in range(inv.shape[0]):
+        blk = kn[t * 128:(t + 1) * 128]
+        assert np.abs(rec[t * 128:(t + 1) * 128] * inv[t] - blk).max() <= 2.0 ** -22 * np.abs(blk).max()
+        assert 2.0 ** 13 <= np.abs(blk).max() / inv[t] < 2.0 ** 14
+    for name in ("b6", "b6dma", "f16x3"):
         assert rel_err(N(res[name][2]), N(res["f32"][2])) < 5e-6, name
         assert (N(res[name][0]) == N(res["f32"][0])).all(), name
+
+
+def test_f16x3_tile_scaling_edge_cases(ops):
+    """fp16x3 scorer on operands whose 128-row tiles differ by many orders of magnitude, with an all-zero tile, a ragged
+    last tile and values far outside the fp16 range: the per-token max logit stays within the fp32 error bound of the
+    float64 result, as tight as the fp32 MFMA chain."""
+    rng = np.random.default_rng(7)
+    R, T = 128 * 9 + 37, 200
+    key = rng.standard_normal((R, 384)).astype(np.float32)
+    tile_scale = np.array([1e-20, 1e-6, 1.0, 0.0, 3e4, 1e9, 2.0 ** -30, 7.0, 1e-3, 1e12], dtype=np.float32)
+    key *= np.repeat(tile_scale, 128)[:R, None]
+    q = np.zeros((1, 256, 384), dtype=np.float32)
+    q[0, :T] = rng.standard_normal((T, 384)).astype(np.float32)
+    q[0, :128] *= 1e-10                                     # the two token halves get their own scale
+    q[0, 128:T] *= 3e-12
+    ref = (q[0, :T].astype(np.float64) @ key.astype(np.float64).T) / np.sqrt(384.0)           # [T,R]
+    bound = (np.abs(q[0, :T]).astype(np.float64) @ np.abs(key).astype(np.float64).T) / np.sqrt(384.0)
+    n_tok = torch.tensor([T], dtype=torch.int32, device="cuda")
+    planes, inv = ops.split_planes_f16(G(key))
+    assert float(inv[3]) == 1.0                             # all-zero tile: scale 1
+    err = {}
+    for name, mode, kp, ks in (("f32", ops.MMA_F32, None, None), ("f16x3", ops.MMA_F16X3, planes, inv)):
+        ops.set_mma_mode(mode)
+        try:
+            _, _, _, stats = ops.score_topk(G(q), n_tok, G(key), 100, want_stats=True, key_planes=kp, key_scale=ks)
+        finally:
+            ops.set_mma_mode(ops.MMA_DEFAULT)
+        mx = N(stats)[0, :T, 0].astype(np.float64)
+        j = ref.argmax(axis=1)
+        err[name] = np.abs(mx - ref[np.arange(T), j]) / bound[np.arange(T), j]
+    assert err["f32"].max() < 4e-7
+    assert err["f16x3"].max() < 4e-7
 
 
 def test_topk_ties_short_and_large(ops, oracle):

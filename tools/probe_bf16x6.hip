@@ -76,3 +76,32 @@ extern "C" int probe_run(const float* A, const float* B, float* D, int K, int mo
   else hipLaunchKernelGGL(k_bf16x6, dim3(1), dim3(64), 0, (hipStream_t)s, A, B, D, K, mode);
   return (int)hipGetLastError();
 }
+
+// ---- fp16 x 3: two fp16 planes per operand (x*2^s = h + l), cross terms l*h + h*l + h*h ----------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ void k_f16x3(const float* A, const float* B, float* D, int K, float sa, float sb, int terms) {
+  int l = threadIdx.x;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    f16x8 ah, al, bh, bl;
+    for (int e = 0; e < 8; ++e) {
+      int k = k0 + 8 * (l >> 5) + e;
+      float x = A[(l & 31) * K + k] * sa;
+      _Float16 h = (_Float16)x; ah[e] = h; al[e] = (_Float16)(x - (float)h);
+      float y = B[(l & 31) * K + k] * sb;
+      _Float16 g = (_Float16)y; bh[e] = g; bl[e] = (_Float16)(y - (float)g);
+    }
+    if (terms >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc, 0, 0, 0);
+    if (terms >= 3) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  }
+  float inv = 1.0f / (sa * sb);
+  for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r] * inv;
+}
+extern "C" int probe_run_f16(const float* A, const float* B, float* D, int K, float sa, float sb, int terms, void* s) {
+  hipLaunchKernelGGL(k_f16x3, dim3(1), dim3(64), 0, (hipStream_t)s, A, B, D, K, sa, sb, terms);
+  return (int)hipGetLastError();
+}
