@@ -450,9 +450,7 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
 // 16 ds_read_b128 and 24 MFMA per slab and wave.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kNsF = 4;                   // ring stages
 constexpr int kStageF = 4 * kRegion;      // A h,l ; B h,l
-constexpr int kRingF = kNsF * kStageF;
 constexpr int kRowF = 12 * 2 * 64;        // 1536 B of planes per operand row
 constexpr int kSlabF = 128;               // bytes per row and slab
 
@@ -465,8 +463,15 @@ struct LogitsF16Args {
   float* logits;
   float* partial;
   int64_t r, ldl;
-  int tiles_per_group, n_tiles, n_groups, b0;
+  int tiles_per_group, n_tiles, n_groups, b0, nb;
 };
+
+// A wave-uniform global load through the scalar cache.  As a plain load hipcc emits global_load_dword (the kernel also
+// stores to global memory, so it cannot prove the location unclobbered) followed by s_waitcnt vmcnt(0) -- which drains
+// every LDS-DMA prefetch in flight.  The constant address space forces s_load_dword (lgkmcnt).
+__device__ __forceinline__ float load_uniform(const float* p) {
+  return *reinterpret_cast<const __attribute__((address_space(4))) float*>((uintptr_t)p);
+}
 
 __device__ __forceinline__ f16x8 lds_read_frag_h(unsigned addr) {
   f16x8 v;
@@ -474,14 +479,18 @@ __device__ __forceinline__ f16x8 lds_read_frag_h(unsigned addr) {
   return v;
 }
 
-__global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
-  __shared__ __attribute__((aligned(1024))) char lds[kRingF + 2 * 128 * 8 + 4 * 64 * 4];
-  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds + kRingF);
-  float* rowmax = reinterpret_cast<float*>(lds + kRingF + 2 * 128 * 8);   // [4 waves][64 rows]
-  const int bl = blockIdx.y;
-  const int b = A.b0 + bl;
+// ABL: debug ablation bits as in k_logits_v2 (0 in production; timing only, results are wrong otherwise)
+// NS: ring stages; NS = 2 (64 KiB) lets two workgroups share a CU, so one's epilogue / DMA issue overlaps the other's MFMAs.
+template <int ABL, int NS>
+__global__ void __launch_bounds__(256, NS == 2 ? 2 : 1) k_logits_f16(LogitsF16Args A) {
+  constexpr int kRingF = NS * kStageF;
+  __shared__ __attribute__((aligned(1024))) char lds[kRingF];
+  // consecutive work items (same XCD after the remap, dispatched together) are the 2 token halves x nb images of ONE ray
+  // tile group: they stream the same key tiles at the same time, so the keys come from HBM once and from L2 2 nb - 1 times
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  const int grp = (int)(w >> 1), m_tile = (int)(w & 1u);
+  const int m_tile = (int)(w & 1u);
+  const int bl = (int)((w >> 1) % (unsigned)A.nb), grp = (int)((w >> 1) / (unsigned)A.nb);
+  const int b = A.b0 + bl;
   const int M = A.n_tok[b];
   const float cq = A.qinv[2 * b + m_tile];
   const int row0 = m_tile * 128;
@@ -489,7 +498,9 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  float m_run = -INFINITY, s_run = 0.f;
+  // running (max, sumexp) of token wm*64 + tm*32 + (lane & 31) over the rays THIS lane has produced (lane>>5 and wn select
+  // which): no cross-lane traffic per tile, the four partials of a token are merged once at the end of the run
+  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
   const int t_begin = grp * A.tiles_per_group;
   const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
   if (row0 < M && t_begin < t_end) {
@@ -515,6 +526,8 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
     // one DMA piece (i = 0..3 key pieces first: HBM; i = 4..7 q pieces: L2) of slab s into ring stage `stage`
     auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {
       char* sbase = lds + stage * kStageF + wave * 1024;
+      if ((ABL & 8) && i < 4) return;      // compile-time: no branches enter the instruction stream
+      if ((ABL & 1) && i >= 4) return;
       if (i < 4) {
         const unsigned ob = (unsigned)min(rowB[i], lim) * kRowF + offB[i] + (unsigned)(s * kSlabF);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (2 + (i >> 1)) * kRegion + (i & 1) * 4096), 16, 0, 0);
@@ -542,8 +555,8 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
         fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
         fb[t][ks] = lds0 + 2 * kRegion + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
       }
-    float* lg = A.logits + (int64_t)bl * kT * A.ldl;
-    const unsigned lane_elem = (unsigned)(4 * (lane >> 5)) * (unsigned)A.ldl + (unsigned)(wn * 64 + (lane & 31));
+    // logits of image bl, blocked: [ray tile][token group g = t / 32][ray quad = (r % 128) / 4][t % 32][r % 4]
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((m_tile * 4 + wm * 2) * 4096 + wn * 2048 + lane * 4);
     const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowF;
     int lim_cur = tile_lim(t_begin);
 
@@ -557,14 +570,13 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
     };
     // prologue of the run: slabs 0..2 of the first tile, B(0), slab 3, fragments (0, ks0).  (A tile has 12 >= 4 slabs.)
-    issue(kcur, lim_cur, 0, 0);
-    issue(kcur, lim_cur, 1, 1);
-    issue(kcur, lim_cur, 2, 2);
-    wait_slab(2);
-    issue(kcur, lim_cur, 3, 3);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue(kcur, lim_cur, i, i);
+    wait_slab(NS - 2);
+    issue(kcur, lim_cur, NS - 1, NS - 1);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -576,9 +588,11 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
 
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int64_t col0 = (int64_t)tile * kBN;
+      // after the last tile of the run the prefetch simply re-reads the current tile (harmless, keeps the slab loop and
+      // its vmcnt bookkeeping free of branches)
       const bool has_next = tile + 1 < t_end;
-      const char* knext = kcur + (int64_t)kBN * kRowF;
-      const int lim_next = has_next ? tile_lim(tile + 1) : 0;
+      const char* knext = has_next ? kcur + (int64_t)kBN * kRowF : kcur;
+      const int lim_next = has_next ? tile_lim(tile + 1) : lim_cur;
       f32x16 acc[2][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -601,8 +615,8 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
           for (int z = 0; z < 4; ++z) {
             const int slot = q * 4 + z;        // 0..11
             const int tm = z >> 1, tn = z & 1;
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[tm][PA[q]], xb[tn][PB[q]], acc[tm][tn], 0, 0, 0);
-            if (do_read && slot < 8) {
+            if (!(ABL & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][tn], 0, 0, 0);
+            if (do_read && !(ABL & 16) && slot < 8) {
               const int op = slot >> 2, t = (slot >> 1) & 1, pp = slot & 1;
               if (op == 0) na[t][pp] = lds_read_frag_h(fa[t][rks] + st + pp * kRegion);
               else nb[t][pp] = lds_read_frag_h(fb[t][rks] + st + pp * kRegion);
@@ -615,81 +629,361 @@ __global__ void __launch_bounds__(256, 1) k_logits_f16(LogitsF16Args A) {
 
       for (int s0 = 0; s0 < 12; s0 += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {     // slab sl = s0 + u sits in ring stage u (12 slabs per tile = 0 mod 4)
+        for (int u = 0; u < 4; ++u) {       // slab sl = s0 + u sits in ring stage u % NS (12 slabs per tile = 0 mod 4)
           const int sl = s0 + u;
-          mfma_step(f0a, f0b, f1a, f1b, true, u, 1, false, nullptr, 0, 0, 0);
+          constexpr int kAhead = NS - 2;    // slabs in flight behind the awaited one
+          mfma_step(f0a, f0b, f1a, f1b, true, u % NS, 1, false, nullptr, 0, 0, 0);
           wait_lds();
-          const bool more = sl < 11 || has_next;
-          if (more) {
-            // slabs issued beyond slab sl+1 at this point: sl+2, sl+3 (when they exist)
-            const int last = has_next ? 11 + 4 : 11;          // last slab index (in this tile's numbering) ever issued
-            const int ahead = min(2, last - (sl + 1));
-            wait_slab(ahead);
-          }
-          const bool dma_same = more && (sl + 4 < 12);
-          const bool dma_next = more && (sl + 4 >= 12) && has_next;
-          if (dma_same) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 4, 0, true, kcur, lim_cur, sl + 4, u);
-          else if (dma_next) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 4, 0, true, knext, lim_next, sl + 4 - 12, u);
-          else mfma_step(f1a, f1b, f0a, f0b, more, (u + 1) % 4, 0, false, nullptr, 0, 0, 0);
+          wait_slab(kAhead);                // slab sl+1 landed everywhere, slab sl's stage is free
+          const bool same = sl + NS < 12;   // scalar selects, no branches
+          mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % NS, 0, true, same ? kcur : knext, same ? lim_cur : lim_next,
+                    same ? sl + NS : sl + NS - 12, u % NS);
           wait_lds();
         }
       }
 
-      // ---- epilogue (as k_logits_v2; the constant undoes both power-of-two operand scales, exactly, and applies 1/sqrt 384)
-      const float cf = (cq * A.kinv[tile]) * kInvSqrtD;
-      const bool v0 = col0 + acc_col(wn, 0, lane) < A.r, v1 = col0 + acc_col(wn, 1, lane) < A.r;
-      float mx[32];
+      if (ABL & 4) {   // keep the fragments alive
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* rowp = lg + (int64_t)(row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2)) * A.ldl + col0;
-          const float l0 = acc[tm][0][r] * cf, l1 = acc[tm][1][r] * cf;
-          acc[tm][0][r] = l0;
-          acc[tm][1][r] = l1;
-          rowp[lane_elem] = l0;
-          rowp[lane_elem + 32u] = l1;
-          mx[tm * 16 + r] = fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY);
-        }
-      const float my_max = transpose_reduce32<true>(mx, lane);
-      float* rmx = rowmax + wave * 64 + (lane >> 5) * 32;
-      rmx[lane & 31] = my_max;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float sm[32];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const float m = rmx[j];
-        const int tm = j >> 4, r = j & 15;
-        const float e0 = v0 ? __expf(acc[tm][0][r] - m) : 0.f, e1 = v1 ? __expf(acc[tm][1][r] - m) : 0.f;
-        sm[j] = (m > -INFINITY) ? e0 + e1 : 0.f;
+        for (int t = 0; t < 2; ++t) acc[t][t][0] += (float)f0a[t][0][0] + (float)f0b[t][1][0];
       }
-      const float my_sum = transpose_reduce32<false>(sm, lane);
-      {
-        const int j = lane & 31;
-        const int lr = acc_row(wm, j >> 4, j & 15, lane);
-        part[wn][lr][0] = my_max;
-        part[wn][lr][1] = my_sum;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tid < 128) {
+      if (ABL & 2) {
+        float sacc = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float mt = part[h][tid][0], st2 = part[h][tid][1];
-          if (mt > -INFINITY) {
-            const float mn = fmaxf(m_run, mt);
-            s_run = s_run * __expf(m_run - mn) + st2 * __expf(mt - mn);
-            m_run = mn;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) lg[lane] = sacc;
+        kcur = knext;
+        lim_cur = lim_next;
+        continue;
+      }
+      // ---- epilogue.  The MFMAs computed K Q^T: lane l holds token (l & 31) and, per accumulator register group rg, the
+      // four consecutive rays 8 rg + 4 (l >> 5) + {0..3} of its 32-ray block -> one 16-byte store per group, and a wave's
+      // store instruction covers 1 KiB of contiguous logits.  The constant undoes both power-of-two operand scales
+      // (exactly) and applies 1/sqrt 384.
+      const float cf = (cq * load_uniform(A.kinv + tile)) * kInvSqrtD;
+      float* tb = lg + (int64_t)tile * (kT * kBN);
+      const bool ragged = lim_cur < kBN - 1;           // only the last ray tile of the scene
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float4 v;
+            v.x = acc[tm][tn][4 * rg + 0] * cf;
+            v.y = acc[tm][tn][4 * rg + 1] * cf;
+            v.z = acc[tm][tn][4 * rg + 2] * cf;
+            v.w = acc[tm][tn][4 * rg + 3] * cf;
+            acc[tm][tn][4 * rg + 0] = v.x;
+            acc[tm][tn][4 * rg + 1] = v.y;
+            acc[tm][tn][4 * rg + 2] = v.z;
+            acc[tm][tn][4 * rg + 3] = v.w;
+            *reinterpret_cast<float4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
           }
+        const float mn = fmaxf(m_run[tm], mx);
+        float sum = 0.f;
+        if (!ragged) {
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += __expf(acc[tm][tn][r] - mn);
+        } else {
+          const int ray0 = wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              sum += (ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur) ? __expf(acc[tm][tn][r] - mn) : 0.f;
+        }
+        s_run[tm] = s_run[tm] * __expf(m_run[tm] - mn) + sum;
+        m_run[tm] = mn;
+      }
+      kcur = knext;
+      lim_cur = lim_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing prefetch
+  }
+  // merge the four partials of every token (2 ray halves of the lane layout x 2 waves wn) through the (now idle) ring
+  __syncthreads();
+  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds);   // [wn * 2 + (lane >> 5)][token][max, sum]
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    float* pp = part[wn * 2 + (lane >> 5)][wm * 64 + tm * 32 + (lane & 31)];
+    pp[0] = m_run[tm];
+    pp[1] = s_run[tm];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float m = -INFINITY, sres = 0.f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float mt = part[h][tid][0], st2 = part[h][tid][1];
+      if (mt > -INFINITY) {
+        const float mn = fmaxf(m, mt);
+        sres = sres * __expf(m - mn) + st2 * __expf(mt - mn);
+        m = mn;
+      }
+    }
+    pout[2 * tid] = m;
+    pout[2 * tid + 1] = sres;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16x3, wide tile: ONE workgroup of 8 waves per CU computes all 256 tokens x 128 rays of a ray tile, so a key slab is
+// fetched once per image (not once per token half), the L2 -> LDS traffic per MFMA drops by a quarter and every SIMD holds
+// two waves whose DMA issue / LDS reads / epilogue overlap each other's MFMAs.  Stage = q planes 2 x [256 rows][64 B] +
+// key planes 2 x [128 rows][64 B] = 48 KiB, ring of 3 (144 KiB): the DMA of slab s+2 is in flight while slab s computes.
+// Wave (wm 0..3, wn 0..1) owns tokens [64 wm, 64 wm + 64) x rays [64 wn, 64 wn + 64) of the tile; 6 DMA pieces, 16
+// ds_read_b128 and 24 MFMA per slab and wave.  Epilogue and logits layout as k_logits_f16.
+// ------------------------------------------------------------------------------------------------
+constexpr int kQRegW = 256 * 64;
+constexpr int kKRegW = 128 * 64;
+constexpr int kStageW = 2 * kQRegW + 2 * kKRegW;
+constexpr int kNsW = 3;
+
+template <int ABL>
+__global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
+  __shared__ __attribute__((aligned(1024))) char lds[kNsW * kStageW];
+  // consecutive work items (same XCD after the remap, dispatched together) are the nb images of ONE ray tile group: they
+  // stream the same key tiles at the same time, so the keys come from HBM once and from L2 nb - 1 times
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bl = (int)(w % (unsigned)A.nb), grp = (int)(w / (unsigned)A.nb);
+  const int b = A.b0 + bl;
+  const int M = A.n_tok[b];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const float cq = A.qinv[2 * b + (wm >> 1)];
+  const bool active = wm * 64 < M;              // waves whose 64 tokens are all padding only feed the ring
+  float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
+  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  const int t_begin = grp * A.tiles_per_group;
+  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+  if (M > 0 && t_begin < t_end) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    // ---- DMA pieces (1 KiB = 16 rows x 64 B, lane-linear in LDS; the 16-byte chunk swizzle is applied on the source side)
+    //      q piece i = 0..3: plane i & 1, rows 16 (wave + 8 (i >> 1)) ..; key piece p = 0..1: plane p, rows 16 wave ..
+    const int prow = lane >> 2, pos = lane & 3;
+    unsigned offQ[4], offK[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * (i >> 1)) * 16 + prow;
+      offQ[i] = (unsigned)min(row, M - 1) * kRowF + (unsigned)((i & 1) * 64 + ((pos ^ ((row >> 2) & 3)) << 4));
+    }
+    const int rowK = wave * 16 + prow;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) offK[pl] = (unsigned)(pl * 64 + ((pos ^ ((rowK >> 2) & 3)) << 4));
+    const char* qbase = A.qp + (int64_t)b * kT * kRowF;
+    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {   // i < 2: key (HBM first)
+      char* sbase = lds + stage * kStageW + wave * 1024;
+      if ((ABL & 8) && i < 2) return;
+      if ((ABL & 1) && i >= 2) return;
+      if (i < 2) {
+        const unsigned ob = (unsigned)min(rowK, lim) * kRowF + offK[i] + (unsigned)(s * kSlabF);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + 2 * kQRegW + i * kKRegW), 16, 0, 0);
+      } else {
+        const int k = i - 2;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offQ[k] + (unsigned)(s * kSlabF))),
+                                         (lds_ptr_t)(sbase + (k & 1) * kQRegW + (k >> 1) * 8192), 16, 0, 0);
+      }
+    };
+    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) issue_piece(kbase, lim, s, stage, i);
+    };
+    auto tile_lim = [&](int tile) {
+      const int64_t left = A.r - (int64_t)tile * kBN - 1;
+      return left < 127 ? (int)left : 127;
+    };
+    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = 2 * ks + (lane >> 5);
+        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
+        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
+        fb[t][ks] = lds0 + 2 * kQRegW + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+      }
+    // logits of image bl, blocked: [ray tile][token group g = t / 32][ray quad = (r % 128) / 4][t % 32][r % 4]
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + wn * 2048 + lane * 4);
+    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowF;
+    int lim_cur = tile_lim(t_begin);
+
+    f16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    auto wait_lds = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_slab = [&]() {     // one younger slab (6 pieces) may stay in flight
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    };
+    issue(kcur, lim_cur, 0, 0);
+    issue(kcur, lim_cur, 1, 1);
+    wait_slab();
+    issue(kcur, lim_cur, 2, 2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        f0a[t][pl] = lds_read_frag_h(fa[t][0] + pl * kQRegW);
+        f0b[t][pl] = lds_read_frag_h(fb[t][0] + pl * kKRegW);
+      }
+    wait_lds();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      // after the last tile of the run the prefetch simply re-reads the current tile (harmless, keeps the slab loop and
+      // its vmcnt bookkeeping free of branches)
+      const bool has_next = tile + 1 < t_end;
+      const char* knext = has_next ? kcur + (int64_t)kBN * kRowF : kcur;
+      const int lim_next = has_next ? tile_lim(tile + 1) : lim_cur;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+      // 12 MFMAs on (xa, xb): l*h, h*l, h*h for the 4 accumulators (C^T = K Q^T: rows = rays, columns = tokens); the 8
+      // fragment reads of the next k-step and the 6 DMA pieces of a later slab ride in the MFMA slots
+      auto mfma_step = [&](f16x8 (&xa)[2][2], f16x8 (&xb)[2][2], f16x8 (&na)[2][2], f16x8 (&nb)[2][2], const int rstage, const int rks,
+                           const bool do_dma, const char* dkb, const int dlim, const int ds, const int dstage) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+        const unsigned st = (unsigned)(rstage * kStageW);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int z = 0; z < 4; ++z) {
+            const int slot = q * 4 + z;        // 0..11
+            const int tm = z >> 1, tn = z & 1;
+            if (!(ABL & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][tn], 0, 0, 0);
+            if (!(ABL & 16) && slot < 8) {
+              const int op = slot >> 2, t = (slot >> 1) & 1, pp = slot & 1;
+              if (op == 0) na[t][pp] = lds_read_frag_h(fa[t][rks] + st + pp * kQRegW);
+              else nb[t][pp] = lds_read_frag_h(fb[t][rks] + st + pp * kKRegW);
+            }
+            if (do_dma && slot < 6) issue_piece(dkb, dlim, ds, dstage, slot);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+
+      for (int s0 = 0; s0 < 12; s0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {       // slab sl = s0 + u sits in ring stage u (12 slabs per tile = 0 mod 3)
+          const int sl = s0 + u;
+          mfma_step(f0a, f0b, f1a, f1b, u, 1, false, nullptr, 0, 0, 0);
+          wait_lds();
+          wait_slab();                      // slab sl+1 landed everywhere, slab sl's stage is free
+          const bool same = sl + kNsW < 12; // scalar selects, no branches
+          mfma_step(f1a, f1b, f0a, f0b, (u + 1) % kNsW, 0, true, same ? kcur : knext, same ? lim_cur : lim_next,
+                    same ? sl + kNsW : sl + kNsW - 12, u);
+          wait_lds();
+        }
+      }
+
+      if (ABL & 2) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) lg[lane] = sacc;
+        kcur = knext;
+        lim_cur = lim_next;
+        continue;
+      }
+      // ---- epilogue (see k_logits_f16): 16-byte stores, 1 KiB contiguous per wave instruction; per-lane running stats
+      if (active) {
+        const float cf = (cq * load_uniform(A.kinv + tile)) * kInvSqrtD;
+        float* tb = lg + (int64_t)tile * (kT * kBN);
+        const bool ragged = lim_cur < kBN - 1;           // only the last ray tile of the scene
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          float mx = -INFINITY;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              float4 v;
+              v.x = acc[tm][tn][4 * rg + 0] * cf;
+              v.y = acc[tm][tn][4 * rg + 1] * cf;
+              v.z = acc[tm][tn][4 * rg + 2] * cf;
+              v.w = acc[tm][tn][4 * rg + 3] * cf;
+              acc[tm][tn][4 * rg + 0] = v.x;
+              acc[tm][tn][4 * rg + 1] = v.y;
+              acc[tm][tn][4 * rg + 2] = v.z;
+              acc[tm][tn][4 * rg + 3] = v.w;
+              if (!(ABL & 64)) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 vv = {v.x, v.y, v.z, v.w};
+                if (ABL & 256) *reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = vv;
+                else __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256));
+              }
+              mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
+            }
+          if (ABL & 128) {
+            m_run[tm] = fmaxf(m_run[tm], mx);
+            continue;
+          }
+          const float mn = fmaxf(m_run[tm], mx);
+          float sum[4] = {0.f, 0.f, 0.f, 0.f};
+          if (!ragged) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sum[r & 3] += __expf(acc[tm][tn][r] - mn);
+          } else {
+            const int ray0 = wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                sum[r & 3] += (ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur) ? __expf(acc[tm][tn][r] - mn) : 0.f;
+          }
+          s_run[tm] = s_run[tm] * __expf(m_run[tm] - mn) + ((sum[0] + sum[1]) + (sum[2] + sum[3]));
+          m_run[tm] = mn;
         }
       }
       kcur = knext;
       lim_cur = lim_next;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing prefetch
   }
-  if (tid < 128) {
-    pout[2 * tid] = m_run;
-    pout[2 * tid + 1] = s_run;
+  // merge the four partials of every token (2 ray halves of the lane layout x 2 waves wn) through the (now idle) ring
+  __syncthreads();
+  float(*part)[256][2] = reinterpret_cast<float(*)[256][2]>(lds);   // [wn * 2 + (lane >> 5)][token][max, sum]
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    float* pp = part[wn * 2 + (lane >> 5)][wm * 64 + tm * 32 + (lane & 31)];
+    pp[0] = m_run[tm];
+    pp[1] = s_run[tm];
+  }
+  __syncthreads();
+  if (tid < 256) {
+    float m = -INFINITY, sres = 0.f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float mt = part[h][tid][0], st2 = part[h][tid][1];
+      if (mt > -INFINITY) {
+        const float mn = fmaxf(m, mt);
+        sres = sres * __expf(m - mn) + st2 * __expf(mt - mn);
+        m = mn;
+      }
+    }
+    pout[2 * tid] = m;
+    pout[2 * tid + 1] = sres;
   }
 }
 
@@ -784,6 +1078,59 @@ __global__ void __launch_bounds__(256) k_score_reduce(const float* __restrict__ 
 #pragma unroll 8
   for (int t = 0; t < T; ++t) s += expf(l[(int64_t)t * ldl] - st[t][0]) / st[t][1];
   scores[(int64_t)bl * score_stride + j] = s;
+}
+
+// pass 2 on the blocked logits of k_logits_f16 ([tile][token group 8][ray quad 32][token 32][ray 4]): a wave owns a pair of
+// ray quads (8 rays): lanes 0..31 / 32..63 hold the 32 tokens of a group for quad 2p / 2p+1, every load instruction reads
+// 1 KiB contiguous, the 8 token groups accumulate in registers and one butterfly over 32 lanes finishes the column sums.
+__global__ void __launch_bounds__(256) k_score_reduce_blocked(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ stats,
+                                                               const int* __restrict__ n_tok, int b0, int64_t R,
+                                                               float* __restrict__ scores, int64_t score_stride) {
+  const int bl = blockIdx.y;
+  const int T = n_tok[b0 + bl];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+  float mt[8], st[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int t = g * 32 + l31;
+    mt[g] = stats[((int64_t)bl * kT + t) * 2];
+    st[g] = stats[((int64_t)bl * kT + t) * 2 + 1];
+  }
+  const int64_t tile = blockIdx.x;
+  const float* tb = logits + (int64_t)bl * kT * ldl + tile * (kT * kBN) + lane * 4;
+  float* out = scores + (int64_t)bl * score_stride + tile * kBN;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = u * 4 + wave;                 // quad pair
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      if (g * 32 + l31 < T) {
+        const float4 v = *reinterpret_cast<const float4*>(tb + g * 4096 + p * 256);
+        acc.x += expf(v.x - mt[g]) / st[g];
+        acc.y += expf(v.y - mt[g]) / st[g];
+        acc.z += expf(v.z - mt[g]) / st[g];
+        acc.w += expf(v.w - mt[g]) / st[g];
+      }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64);
+      acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64);
+      acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (l31 == 0) {
+      const int64_t r0 = tile * kBN + p * 8 + (lane >> 5) * 4;
+      float* o4 = out + p * 8 + (lane >> 5) * 4;
+      if (r0 + 3 < R && ((uintptr_t)o4 & 15) == 0) *reinterpret_cast<float4*>(o4) = acc;
+      else {   // ragged end of the scene, or a caller buffer whose row stride R is not a multiple of 4
+        if (r0 < R) o4[0] = acc.x;
+        if (r0 + 1 < R) o4[1] = acc.y;
+        if (r0 + 2 < R) o4[2] = acc.z;
+        if (r0 + 3 < R) o4[3] = acc.w;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1119,8 +1466,38 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
           hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q + (int64_t)b0 * kT * SIXDGS_D,
                              (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes, qinv);
           LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)key_planes, qinv - 2 * b0, d_key_scale, logits,
-                             partial, r, A.ldl, p.tiles_per_group, p.n_tiles, p.n_groups, b0};
-          hipLaunchKernelGGL(k_logits_f16, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, V);
+                             partial, r, A.ldl, p.tiles_per_group, p.n_tiles, p.n_groups, b0, nb};
+          const char* kv = getenv("SIXDGS_F16_KERNEL");   // evaluation switch: w (default) | ns2 | ns4
+          if (!kv || kv[0] == 'w') {
+            auto kern = k_logits_f16w<0>;
+#ifdef SIXDGS_ABLATION
+            if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
+#define SDG_ABL_CASE(n) case n: kern = k_logits_f16w<n>; break;
+              switch (atoi(ab)) {
+                SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
+                SDG_ABL_CASE(18) SDG_ABL_CASE(10) SDG_ABL_CASE(3) SDG_ABL_CASE(64) SDG_ABL_CASE(128) SDG_ABL_CASE(192) SDG_ABL_CASE(256)
+                default: break;
+              }
+#undef SDG_ABL_CASE
+            }
+#endif
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_groups * nb)), dim3(512), 0, s, V);
+          } else {
+            const bool ns2 = kv[2] == '2';
+            auto kern = ns2 ? k_logits_f16<0, 2> : k_logits_f16<0, 4>;
+#ifdef SIXDGS_ABLATION
+            if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
+#define SDG_ABL_CASE(n) case n: kern = ns2 ? k_logits_f16<n, 2> : k_logits_f16<n, 4>; break;
+              switch (atoi(ab)) {
+                SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
+                SDG_ABL_CASE(18) SDG_ABL_CASE(10) SDG_ABL_CASE(3)
+                default: break;
+              }
+#undef SDG_ABL_CASE
+            }
+#endif
+            hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_groups * 2 * nb)), dim3(256), 0, s, V);
+          }
         } else if (use_v2) {
           // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
           hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,
@@ -1155,8 +1532,12 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
         }
       }
       hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
-      hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
-                         d_n_tok, b0, r, sc, sc_stride);
+      if (use_f16)
+        hipLaunchKernelGGL(k_score_reduce_blocked, dim3((unsigned)p.n_tiles, (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats, d_n_tok,
+                           b0, r, sc, sc_stride);
+      else
+        hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
+                           d_n_tok, b0, r, sc, sc_stride);
       SDG_LAUNCH_OK();
       if (row_stats) {
         hipError_t e = hipMemcpyAsync(row_stats + (int64_t)b0 * kT * 2, stats, (size_t)nb * kT * 2 * sizeof(float),

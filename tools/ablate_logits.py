@@ -16,17 +16,19 @@ ops = importlib.import_module("6dgs_amd.ops")
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 6_400_000
 torch.manual_seed(0)
 key = torch.randn(R, 384, device="cuda")
-planes = ops.split_planes(key)
+F16 = os.environ.get("ABLATE_MODE", "f16x3") == "f16x3"
+ops.set_mma_mode(ops.MMA_F16X3 if F16 else ops.MMA_BF16X6)
+planes, kscale = ops.split_planes_f16(key) if F16 else (ops.split_planes(key), None)
 del key
 q = torch.randn(2, 256, 384, device="cuda")
 n_tok = torch.full((2,), 256, dtype=torch.int32, device="cuda")
 ws = torch.empty(ops.score_topk_workspace_bytes(R, 2, 100), dtype=torch.uint8, device="cuda")
-names = {0: "full", 1: "Q DMA first tile only", 8: "key DMA first tile only", 9: "no DMA after first tile", 2: "no epilogue",
-         4: "no MFMA", 6: "no MFMA, no epilogue", 11: "no DMA, no epilogue", 27: "MFMA + barriers only (no DMA/reads/epilogue)", 18: "no frag reads, no epilogue"}
-for abl in (0, 1, 8, 9, 2, 4, 11, 27):
+names = {256: "plain (temporal) stores", 64: "no logit stores", 128: "no exp/sum stats", 192: "no stores, no exp/sum", 3: "no Q DMA, no epilogue", 10: "no key DMA, no epilogue", 59: "MFMA only (no DMA/reads/epilogue/barriers)", 0: "full", 1: "Q DMA first tile only", 8: "key DMA first tile only", 9: "no DMA after first tile", 2: "no epilogue",
+         4: "no MFMA", 13: "no MFMA, no DMA after first tile", 6: "no MFMA, no epilogue", 11: "no DMA, no epilogue", 27: "MFMA + barriers only (no DMA/reads/epilogue)", 18: "no frag reads, no epilogue"}
+for abl in (0, 256, 64):
     os.environ["SIXDGS_DEBUG_ABLATE"] = str(abl)
     for it in range(2):
         prof = ops.KernelProfile()
-        ops.score_topk(q, n_tok, None, 100, want_scores=False, workspace=ws, key_planes=planes, profile=prof, n_tok_host=[256, 256])
+        ops.score_topk(q, n_tok, None, 100, want_scores=False, workspace=ws, key_planes=planes, key_scale=kscale, profile=prof, n_tok_host=[256, 256])
         ms, fl, by, n = prof.collect()
     print(f"ABL={abl:3d} {names[abl]:34s} {ms:8.2f} ms   {fl / ms / 1e9:7.1f} TFLOP/s-eq   per WG-tile {ms * 1e3 * 256 / (R / 128 * 4):6.2f} us")
