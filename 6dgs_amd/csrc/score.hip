@@ -441,16 +441,12 @@ __global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
 // pass 1, fp16x3 variant (SIXDGS_MMA_F16X3): TWO scaled fp16 planes per operand, THREE cross terms.
 // x * 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h): fp16 carries 11 significant bits, so h + l reproduces
 // x to 2^-23 and l*h + h*l + h*h to ~2^-22 per product (every fp16 x fp16 product is exact in fp32).  The power-of-two
-// scale (one per key set, one per image on the q side; chosen so that max|x| 2^s is in [2^13, 2^14]) keeps h and l in
-// fp16's normal range for everything within 2^-17 of the largest value and is undone exactly by the epilogue constant.
-// Measured (tools/probe_f16x3.py, K = 384): 1.0e-7 * sum|a||b|, below both the fp32 MFMA chain (1.6e-7) and bf16x6.
-// Half the MFMA instructions of bf16x6 and 2/3 of its operand bytes (1536 B per row, the size of fp32).
-// Same structure as k_logits_v2; geometry: 4 regions (A planes 0,1; B planes 0,1) of 128 rows x 64 B per 32-k slab =
-// 32 KiB per stage, 4-stage ring (128 KiB) -> the DMA of slab s+3 is issued after the barrier of slab s; 8 DMA pieces,
-// 16 ds_read_b128 and 24 MFMA per slab and wave.
+// scale (one per 128-row tile of either operand, chosen so that the tile's max|x| 2^s is in [2^13, 2^14)) keeps h and l
+// in fp16's normal range for everything within 2^-17 of the tile's largest value and is undone exactly by the epilogue
+// constant.  Measured (tools/probe_f16x3.py, K = 384): 1.0e-7 * sum|a||b|, below both the fp32 MFMA chain (1.6e-7) and
+// bf16x6.  Half the MFMA instructions of bf16x6 and 2/3 of its operand bytes (1536 B per row, the size of fp32).
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kStageF = 4 * kRegion;      // A h,l ; B h,l
 constexpr int kRowF = 12 * 2 * 64;        // 1536 B of planes per operand row
 constexpr int kSlabF = 128;               // bytes per row and slab
 
@@ -479,279 +475,43 @@ __device__ __forceinline__ f16x8 lds_read_frag_h(unsigned addr) {
   return v;
 }
 
-// ABL: debug ablation bits as in k_logits_v2 (0 in production; timing only, results are wrong otherwise)
-// NS: ring stages; NS = 2 (64 KiB) lets two workgroups share a CU, so one's epilogue / DMA issue overlaps the other's MFMAs.
-template <int ABL, int NS>
-__global__ void __launch_bounds__(256, NS == 2 ? 2 : 1) k_logits_f16(LogitsF16Args A) {
-  constexpr int kRingF = NS * kStageF;
-  __shared__ __attribute__((aligned(1024))) char lds[kRingF];
-  // consecutive work items (same XCD after the remap, dispatched together) are the 2 token halves x nb images of ONE ray
-  // tile group: they stream the same key tiles at the same time, so the keys come from HBM once and from L2 2 nb - 1 times
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  const int m_tile = (int)(w & 1u);
-  const int bl = (int)((w >> 1) % (unsigned)A.nb), grp = (int)((w >> 1) / (unsigned)A.nb);
-  const int b = A.b0 + bl;
-  const int M = A.n_tok[b];
-  const float cq = A.qinv[2 * b + m_tile];
-  const int row0 = m_tile * 128;
-  float* pout = A.partial + (((int64_t)bl * A.n_groups + grp) * kT + row0) * 2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  // running (max, sumexp) of token wm*64 + tm*32 + (lane & 31) over the rays THIS lane has produced (lane>>5 and wn select
-  // which): no cross-lane traffic per tile, the four partials of a token are merged once at the end of the run
-  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
-  const int t_begin = grp * A.tiles_per_group;
-  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
-  if (row0 < M && t_begin < t_end) {
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    // ---- DMA pieces: piece i of this wave is 1-KiB block 4 (i & 1) + wave of region (i >> 1): A h, A l, B h, B l ------
-    unsigned offA[4], offB[4];
-    int rowB[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int sub = 4 * (i & 1) + wave;
-      const int chunk = sub * 64 + lane;
-      const int row = chunk >> 2, pos = chunk & 3;
-      const int c = pos ^ ((row >> 2) & 3);
-      const unsigned inrow = (unsigned)(((i >> 1) & 1) * 64 + c * 16);
-      if (i < 4) {
-        offA[i] = (unsigned)min(row0 + row, M - 1) * kRowF + inrow;
-      } else {
-        rowB[i - 4] = row;
-        offB[i - 4] = inrow;
-      }
-    }
-    const char* qbase = A.qp + (int64_t)b * kT * kRowF;
-    // one DMA piece (i = 0..3 key pieces first: HBM; i = 4..7 q pieces: L2) of slab s into ring stage `stage`
-    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {
-      char* sbase = lds + stage * kStageF + wave * 1024;
-      if ((ABL & 8) && i < 4) return;      // compile-time: no branches enter the instruction stream
-      if ((ABL & 1) && i >= 4) return;
-      if (i < 4) {
-        const unsigned ob = (unsigned)min(rowB[i], lim) * kRowF + offB[i] + (unsigned)(s * kSlabF);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (2 + (i >> 1)) * kRegion + (i & 1) * 4096), 16, 0, 0);
-      } else {
-        const int k = i - 4;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[k] + (unsigned)(s * kSlabF))),
-                                         (lds_ptr_t)(sbase + (k >> 1) * kRegion + (k & 1) * 4096), 16, 0, 0);
-      }
-    };
-    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) issue_piece(kbase, lim, s, stage, i);
-    };
-    auto tile_lim = [&](int tile) {
-      const int64_t left = A.r - (int64_t)tile * kBN - 1;
-      return left < 127 ? (int)left : 127;
-    };
-    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = 2 * ks + (lane >> 5);
-        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
-        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
-        fb[t][ks] = lds0 + 2 * kRegion + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
-      }
-    // logits of image bl, blocked: [ray tile][token group g = t / 32][ray quad = (r % 128) / 4][t % 32][r % 4]
-    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((m_tile * 4 + wm * 2) * 4096 + wn * 2048 + lane * 4);
-    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowF;
-    int lim_cur = tile_lim(t_begin);
-
-    f16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
-    auto wait_lds = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // slabs still in flight BEHIND the awaited one: 2 in steady state (ring of 4), fewer at the end of the run
-    auto wait_slab = [&](int ahead) {
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
-    };
-    // prologue of the run: slabs 0..2 of the first tile, B(0), slab 3, fragments (0, ks0).  (A tile has 12 >= 4 slabs.)
-#pragma unroll
-    for (int i = 0; i < NS - 1; ++i) issue(kcur, lim_cur, i, i);
-    wait_slab(NS - 2);
-    issue(kcur, lim_cur, NS - 1, NS - 1);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        f0a[t][p] = lds_read_frag_h(fa[t][0] + p * kRegion);
-        f0b[t][p] = lds_read_frag_h(fb[t][0] + p * kRegion);
-      }
-    wait_lds();
-
-    for (int tile = t_begin; tile < t_end; ++tile) {
-      const int64_t col0 = (int64_t)tile * kBN;
-      // after the last tile of the run the prefetch simply re-reads the current tile (harmless, keeps the slab loop and
-      // its vmcnt bookkeeping free of branches)
-      const bool has_next = tile + 1 < t_end;
-      const char* knext = has_next ? kcur + (int64_t)kBN * kRowF : kcur;
-      const int lim_next = has_next ? tile_lim(tile + 1) : lim_cur;
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-      // 12 MFMAs on (xa, xb): l*h, h*l, h*h for the 4 accumulators; side work rides in the MFMA slots: the 8 fragment
-      // reads of the next k-step (slots 0..7) and optionally the 8 DMA pieces of a later slab (slots 0..7).
-      auto mfma_step = [&](f16x8 (&xa)[2][2], f16x8 (&xb)[2][2], f16x8 (&na)[2][2], f16x8 (&nb)[2][2], const bool do_read,
-                           const int rstage, const int rks, const bool do_dma, const char* dkb, const int dlim, const int ds,
-                           const int dstage) {
-        constexpr int PA[3] = {1, 0, 0};
-        constexpr int PB[3] = {0, 1, 0};
-        const unsigned st = (unsigned)(rstage * kStageF);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-          for (int z = 0; z < 4; ++z) {
-            const int slot = q * 4 + z;        // 0..11
-            const int tm = z >> 1, tn = z & 1;
-            if (!(ABL & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][tn], 0, 0, 0);
-            if (do_read && !(ABL & 16) && slot < 8) {
-              const int op = slot >> 2, t = (slot >> 1) & 1, pp = slot & 1;
-              if (op == 0) na[t][pp] = lds_read_frag_h(fa[t][rks] + st + pp * kRegion);
-              else nb[t][pp] = lds_read_frag_h(fb[t][rks] + st + pp * kRegion);
-            }
-            if (do_dma && slot < 8) issue_piece(dkb, dlim, ds, dstage, slot);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      };
-
-      for (int s0 = 0; s0 < 12; s0 += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {       // slab sl = s0 + u sits in ring stage u % NS (12 slabs per tile = 0 mod 4)
-          const int sl = s0 + u;
-          constexpr int kAhead = NS - 2;    // slabs in flight behind the awaited one
-          mfma_step(f0a, f0b, f1a, f1b, true, u % NS, 1, false, nullptr, 0, 0, 0);
-          wait_lds();
-          wait_slab(kAhead);                // slab sl+1 landed everywhere, slab sl's stage is free
-          const bool same = sl + NS < 12;   // scalar selects, no branches
-          mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % NS, 0, true, same ? kcur : knext, same ? lim_cur : lim_next,
-                    same ? sl + NS : sl + NS - 12, u % NS);
-          wait_lds();
-        }
-      }
-
-      if (ABL & 4) {   // keep the fragments alive
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t][t][0] += (float)f0a[t][0][0] + (float)f0b[t][1][0];
-      }
-      if (ABL & 2) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 12345.678f) lg[lane] = sacc;
-        kcur = knext;
-        lim_cur = lim_next;
-        continue;
-      }
-      // ---- epilogue.  The MFMAs computed K Q^T: lane l holds token (l & 31) and, per accumulator register group rg, the
-      // four consecutive rays 8 rg + 4 (l >> 5) + {0..3} of its 32-ray block -> one 16-byte store per group, and a wave's
-      // store instruction covers 1 KiB of contiguous logits.  The constant undoes both power-of-two operand scales
-      // (exactly) and applies 1/sqrt 384.
-      const float cf = (cq * load_uniform(A.kinv + tile)) * kInvSqrtD;
-      float* tb = lg + (int64_t)tile * (kT * kBN);
-      const bool ragged = lim_cur < kBN - 1;           // only the last ray tile of the scene
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float4 v;
-            v.x = acc[tm][tn][4 * rg + 0] * cf;
-            v.y = acc[tm][tn][4 * rg + 1] * cf;
-            v.z = acc[tm][tn][4 * rg + 2] * cf;
-            v.w = acc[tm][tn][4 * rg + 3] * cf;
-            acc[tm][tn][4 * rg + 0] = v.x;
-            acc[tm][tn][4 * rg + 1] = v.y;
-            acc[tm][tn][4 * rg + 2] = v.z;
-            acc[tm][tn][4 * rg + 3] = v.w;
-            *reinterpret_cast<float4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = v;
-            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
-          }
-        const float mn = fmaxf(m_run[tm], mx);
-        float sum = 0.f;
-        if (!ragged) {
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += __expf(acc[tm][tn][r] - mn);
-        } else {
-          const int ray0 = wn * 64 + 4 * (lane >> 5);
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              sum += (ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur) ? __expf(acc[tm][tn][r] - mn) : 0.f;
-        }
-        s_run[tm] = s_run[tm] * __expf(m_run[tm] - mn) + sum;
-        m_run[tm] = mn;
-      }
-      kcur = knext;
-      lim_cur = lim_next;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing prefetch
-  }
-  // merge the four partials of every token (2 ray halves of the lane layout x 2 waves wn) through the (now idle) ring
-  __syncthreads();
-  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds);   // [wn * 2 + (lane >> 5)][token][max, sum]
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    float* pp = part[wn * 2 + (lane >> 5)][wm * 64 + tm * 32 + (lane & 31)];
-    pp[0] = m_run[tm];
-    pp[1] = s_run[tm];
-  }
-  __syncthreads();
-  if (tid < 128) {
-    float m = -INFINITY, sres = 0.f;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const float mt = part[h][tid][0], st2 = part[h][tid][1];
-      if (mt > -INFINITY) {
-        const float mn = fmaxf(m, mt);
-        sres = sres * __expf(m - mn) + st2 * __expf(mt - mn);
-        m = mn;
-      }
-    }
-    pout[2 * tid] = m;
-    pout[2 * tid + 1] = sres;
-  }
+__device__ __forceinline__ f16x8 lds_read_frag_h_off(unsigned addr, const int imm) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
+  return v;
 }
 
+#ifdef SIXDGS_ABLATION
+__device__ unsigned long long g_dbg_cycles[8][8];   // [wave][phase] summed over the blocks with grp == 0 (timing variant)
+#endif
 // ------------------------------------------------------------------------------------------------
-// fp16x3, wide tile: ONE workgroup of 8 waves per CU computes all 256 tokens x 128 rays of a ray tile, so a key slab is
-// fetched once per image (not once per token half), the L2 -> LDS traffic per MFMA drops by a quarter and every SIMD holds
-// two waves whose DMA issue / LDS reads / epilogue overlap each other's MFMAs.  Stage = q planes 2 x [256 rows][64 B] +
-// key planes 2 x [128 rows][64 B] = 48 KiB, ring of 3 (144 KiB): the DMA of slab s+2 is in flight while slab s computes.
-// Wave (wm 0..3, wn 0..1) owns tokens [64 wm, 64 wm + 64) x rays [64 wn, 64 wn + 64) of the tile; 6 DMA pieces, 16
-// ds_read_b128 and 24 MFMA per slab and wave.  Epilogue and logits layout as k_logits_f16.
+// fp16x3 logits kernel, 256 tokens x 256 rays per tile, one workgroup of 8 waves per CU.
+// How it got this shape (all measured on MI355X, tools/ablate_logits.py; DESIGN.md section 3b has the numbers):
+//  * 128 x 128 tiles / 4 waves (the bf16x6 structure): every non-MFMA cycle is exposed with one wave per SIMD;
+//  * the reference orientation Q K^T leaves a lane with one ray column and 16 token rows: 64 four-byte stores per lane
+//    and two 31-step cross-lane reductions per tile for the row statistics.  Computing K Q^T instead gives a lane ONE
+//    token and runs of 4 consecutive rays: 16-byte stores that are 1 KiB contiguous per wave instruction, and running
+//    (max, sumexp) per lane with no cross-lane traffic at all until the end of the run;
+//  * cycle stamps then showed the CU's vector-memory issue port as the limiter (~40 cycles per 1-KiB DMA piece or
+//    store; waves queue on it while the matrix pipe idles), so the tile grew to 256 x 256: 64 DMA pieces per 32-k slab
+//    for 65 536 outputs (256 x 128: 48 for 32 768), 12 ds_read_b128 per 24 MFMA (8 per 12);
+//  * with that the matrix pipe is busy ~85 % of the cycles of the slab loop and the chip is at its power limit
+//    (GRBM_GUI_ACTIVE / duration = 1.36 GHz effective clock under this kernel).
+//   wave (wm 0..3, wn 0..1): tokens [64 wm, +64) x rays [128 wn, +128) of the tile: acc[2][4] = 128 registers
+//   LDS (160 KiB exactly): q slabs  [plane 2][stage 2][256 rows][64 B] at 0       (from L2: 2-stage ring)
+//                          key slabs [stage 3][plane 2][256 rows][64 B] at 64 KiB (from HBM: 3-stage ring)
+//   per slab and wave: 4 steps of 12 MFMA (k-step x ray half); fragments for the next step are read during the current
+//   one (A: 2 x 2 planes per k-step; B: 2 ray blocks x 2 planes per step); the 8 DMA pieces (q of slab+2, key of slab+3)
+//   are issued in step 3, after the slab barrier.
 // ------------------------------------------------------------------------------------------------
-constexpr int kQRegW = 256 * 64;
-constexpr int kKRegW = 128 * 64;
-constexpr int kStageW = 2 * kQRegW + 2 * kKRegW;
-constexpr int kNsW = 3;
+constexpr int kBNX = 256;                // rays per tile
+constexpr int kQStageX = 256 * 64;       // one plane of one stage
+constexpr int kKBaseX = 4 * kQStageX;    // 64 KiB
+constexpr int kLdsX = kKBaseX + 6 * kQStageX;   // 160 KiB
 
 template <int ABL>
-__global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
-  __shared__ __attribute__((aligned(1024))) char lds[kNsW * kStageW];
-  // consecutive work items (same XCD after the remap, dispatched together) are the nb images of ONE ray tile group: they
-  // stream the same key tiles at the same time, so the keys come from HBM once and from L2 nb - 1 times
+__global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   const int bl = (int)(w % (unsigned)A.nb), grp = (int)(w / (unsigned)A.nb);
   const int b = A.b0 + bl;
@@ -760,81 +520,106 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const float cq = A.qinv[2 * b + (wm >> 1)];
-  const bool active = wm * 64 < M;              // waves whose 64 tokens are all padding only feed the ring
+  const bool active = wm * 64 < M;
   float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
   float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  // A.n_tiles / A.tiles_per_group count 256-ray tiles here
   const int t_begin = grp * A.tiles_per_group;
   const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+  const int n_tiles128 = (int)((A.r + 127) >> 7);
   if (M > 0 && t_begin < t_end) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    // ---- DMA pieces (1 KiB = 16 rows x 64 B, lane-linear in LDS; the 16-byte chunk swizzle is applied on the source side)
-    //      q piece i = 0..3: plane i & 1, rows 16 (wave + 8 (i >> 1)) ..; key piece p = 0..1: plane p, rows 16 wave ..
-    const int prow = lane >> 2, pos = lane & 3;
-    unsigned offQ[4], offK[2];
+    // ---- DMA pieces: 1 KiB = 8 rows x 128 B = the two 64-byte planes of a (row, slab), i.e. 8 FULL 128-byte lines per
+    //      instruction (16 half lines with a plane-major mapping -- the vector-memory port is the limiter, and its cost
+    //      follows the number of lines touched).  LDS image [256 rows][128 B] per operand and stage, lane-linear; the eight
+    //      16-byte chunks of a row (plane * 4 + k-chunk) are XOR-swizzled with (row >> 1) & 7 on the source side, which
+    //      makes the 16 lanes of every ds_read_b128 group hit 16 distinct bank groups.
+    //      piece i = 0..3 of either operand: rows 8 (4 wave + i) ..
+    const int prow = lane >> 3, pos8 = lane & 7;
+    unsigned offQ[4], offK[4];
+    int rowK[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = (wave + 8 * (i >> 1)) * 16 + prow;
-      offQ[i] = (unsigned)min(row, M - 1) * kRowF + (unsigned)((i & 1) * 64 + ((pos ^ ((row >> 2) & 3)) << 4));
+      const int row = (wave * 4 + i) * 8 + prow;
+      const unsigned inrow = (unsigned)((pos8 ^ ((row >> 1) & 7)) << 4);   // (plane * 64 + chunk * 16) of the source row-slab
+      offQ[i] = (unsigned)min(row, M - 1) * kRowF + inrow;
+      offK[i] = inrow;
+      rowK[i] = row;
     }
-    const int rowK = wave * 16 + prow;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) offK[pl] = (unsigned)(pl * 64 + ((pos ^ ((rowK >> 2) & 3)) << 4));
     const char* qbase = A.qp + (int64_t)b * kT * kRowF;
-    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {   // i < 2: key (HBM first)
-      char* sbase = lds + stage * kStageW + wave * 1024;
-      if ((ABL & 8) && i < 2) return;
-      if ((ABL & 1) && i >= 2) return;
-      if (i < 2) {
-        const unsigned ob = (unsigned)min(rowK, lim) * kRowF + offK[i] + (unsigned)(s * kSlabF);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + 2 * kQRegW + i * kKRegW), 16, 0, 0);
-      } else {
-        const int k = i - 2;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offQ[k] + (unsigned)(s * kSlabF))),
-                                         (lds_ptr_t)(sbase + (k & 1) * kQRegW + (k >> 1) * 8192), 16, 0, 0);
-      }
+    auto issue_q = [&](const int s, const int qstage, const int i) {
+      if (ABL & 1) return;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offQ[i] + (unsigned)(s * kSlabF))),
+                                       (lds_ptr_t)(lds + qstage * (2 * kQStageX) + (wave * 4 + i) * 1024), 16, 0, 0);
     };
-    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) issue_piece(kbase, lim, s, stage, i);
+    auto issue_k = [&](const char* kbase, int lim, const int s, const int kstage, const int i) {
+      if (ABL & 8) return;
+      const unsigned ob = (unsigned)min(rowK[i], lim) * kRowF + offK[i] + (unsigned)(s * kSlabF);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob),
+                                       (lds_ptr_t)(lds + kKBaseX + kstage * (2 * kQStageX) + (wave * 4 + i) * 1024), 16, 0, 0);
     };
     auto tile_lim = [&](int tile) {
-      const int64_t left = A.r - (int64_t)tile * kBN - 1;
-      return left < 127 ? (int)left : 127;
+      const int64_t left = A.r - (int64_t)tile * kBNX - 1;
+      return left < kBNX - 1 ? (int)left : kBNX - 1;
     };
-    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
+    // fragment addresses per (k-step, plane): row block t adds 32 rows = 4096 B (the swizzle term (row >> 1) & 7 does not
+    // depend on t), so row block and stage go into the 16-bit offset field of ds_read; fb2 = fb + 64 KiB (key stage 2)
+    unsigned fa[2][2], fb[2][2], fb2[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = 2 * ks + (lane >> 5);
-        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
-        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
-        fb[t][ks] = lds0 + 2 * kQRegW + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
+      for (int pl = 0; pl < 2; ++pl) {
+        const int c8 = pl * 4 + 2 * ks + (lane >> 5);
+        const int ra = wm * 64 + (lane & 31), rb = wn * 128 + (lane & 31);
+        fa[ks][pl] = lds0 + ra * 128 + ((c8 ^ ((ra >> 1) & 7)) << 4);
+        fb[ks][pl] = lds0 + kKBaseX + rb * 128 + ((c8 ^ ((rb >> 1) & 7)) << 4);
+        fb2[ks][pl] = fb[ks][pl] + 65536u;
       }
-    // logits of image bl, blocked: [ray tile][token group g = t / 32][ray quad = (r % 128) / 4][t % 32][r % 4]
-    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + wn * 2048 + lane * 4);
-    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowF;
+    auto read_a = [&](const int t, const int ks, const int pl, const int qstage) {
+      return lds_read_frag_h_off(fa[ks][pl], qstage * (2 * kQStageX) + t * 4096);
+    };
+    auto read_b = [&](const int t, const int ks, const int pl, const int kstage) {
+      const int off = kstage * (2 * kQStageX) + t * 4096;
+      return off < 65536 ? lds_read_frag_h_off(fb[ks][pl], off & 65535) : lds_read_frag_h_off(fb2[ks][pl], off & 65535);
+    };
+    // logits of image bl, blocked by 128-ray tiles: [tile128][token group g = t / 32][ray quad][t % 32][r % 4]
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + lane * 4);
+    const char* kcur = A.kp + (int64_t)t_begin * kBNX * kRowF;
     int lim_cur = tile_lim(t_begin);
 
-    f16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];
+    f16x8 a0[2][2], a1[2][2], b0[2][2], b1[2][2];   // [row block][plane]
     auto wait_lds = [&]() {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto wait_slab = [&]() {     // one younger slab (6 pieces) may stay in flight
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+    // timing variant (ABL & 2048): phase p accumulates the cycles since the previous stamp (0 loop overhead, 1 steps 0-2,
+    // 2 vmcnt wait, 3 barrier, 4 step 3, 5 epilogue)
+    unsigned long long t_prev = 0, t_acc[6] = {0, 0, 0, 0, 0, 0};
+    auto tstamp = [&](const int ph) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      t_acc[ph] += now - t_prev;
+      t_prev = now;
     };
-    issue(kcur, lim_cur, 0, 0);
-    issue(kcur, lim_cur, 1, 1);
-    wait_slab();
-    issue(kcur, lim_cur, 2, 2);
+    if (ABL & 2048) t_prev = __builtin_readcyclecounter();
+    // ---- prologue: key slabs 0, 1, 2 and q slabs 0, 1 in the steady-state order (q of a batch before its key) ----------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(kcur, lim_cur, 0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_q(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(kcur, lim_cur, 1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_q(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(kcur, lim_cur, 2, 2, i);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
-        f0a[t][pl] = lds_read_frag_h(fa[t][0] + pl * kQRegW);
-        f0b[t][pl] = lds_read_frag_h(fb[t][0] + pl * kKRegW);
+        a0[t][pl] = read_a(t, 0, pl, 0);
+        b0[t][pl] = read_b(t, 0, pl, 0);
       }
     wait_lds();
 
@@ -842,53 +627,76 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
       // after the last tile of the run the prefetch simply re-reads the current tile (harmless, keeps the slab loop and
       // its vmcnt bookkeeping free of branches)
       const bool has_next = tile + 1 < t_end;
-      const char* knext = has_next ? kcur + (int64_t)kBN * kRowF : kcur;
+      const char* knext = has_next ? kcur + (int64_t)kBNX * kRowF : kcur;
       const int lim_next = has_next ? tile_lim(tile + 1) : lim_cur;
-      f32x16 acc[2][2];
+      // the 12 slabs are fully unrolled; keep the per-slab source addresses from being hoisted out of the tile loop
+      asm volatile("" : "+v"(offQ[0]), "+v"(offQ[1]), "+v"(offQ[2]), "+v"(offQ[3]), "+v"(offK[0]), "+v"(offK[1]), "+v"(offK[2]), "+v"(offK[3]));
+      f32x16 acc[2][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-      // 12 MFMAs on (xa, xb): l*h, h*l, h*h for the 4 accumulators (C^T = K Q^T: rows = rays, columns = tokens); the 8
-      // fragment reads of the next k-step and the 6 DMA pieces of a later slab ride in the MFMA slots
-      auto mfma_step = [&](f16x8 (&xa)[2][2], f16x8 (&xb)[2][2], f16x8 (&na)[2][2], f16x8 (&nb)[2][2], const int rstage, const int rks,
-                           const bool do_dma, const char* dkb, const int dlim, const int ds, const int dstage) {
+      // One step: 12 MFMAs (l*h, h*l, h*h for 2 token blocks x 2 ray blocks of ray half `h`) on A fragments xa and B
+      // fragments xb (C^T = K Q^T: rows = rays, columns = tokens); `side(slot)` places the reads / DMA of the step.
+      auto mfma_step = [&](f16x8 (&xa)[2][2], f16x8 (&xb)[2][2], const int h, auto side) {
         constexpr int PA[3] = {1, 0, 0};
         constexpr int PB[3] = {0, 1, 0};
-        const unsigned st = (unsigned)(rstage * kStageW);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
           for (int z = 0; z < 4; ++z) {
-            const int slot = q * 4 + z;        // 0..11
             const int tm = z >> 1, tn = z & 1;
-            if (!(ABL & 4)) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][tn], 0, 0, 0);
-            if (!(ABL & 16) && slot < 8) {
-              const int op = slot >> 2, t = (slot >> 1) & 1, pp = slot & 1;
-              if (op == 0) na[t][pp] = lds_read_frag_h(fa[t][rks] + st + pp * kQRegW);
-              else nb[t][pp] = lds_read_frag_h(fb[t][rks] + st + pp * kKRegW);
-            }
-            if (do_dma && slot < 6) issue_piece(dkb, dlim, ds, dstage, slot);
+            if (!(ABL & 4))
+              acc[tm][2 * h + tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][2 * h + tn], 0, 0, 0);
+            side(q * 4 + z);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       };
 
-      for (int s0 = 0; s0 < 12; s0 += 3) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {       // slab sl = s0 + u sits in ring stage u (12 slabs per tile = 0 mod 3)
-          const int sl = s0 + u;
-          mfma_step(f0a, f0b, f1a, f1b, u, 1, false, nullptr, 0, 0, 0);
-          wait_lds();
-          wait_slab();                      // slab sl+1 landed everywhere, slab sl's stage is free
-          const bool same = sl + kNsW < 12; // scalar selects, no branches
-          mfma_step(f1a, f1b, f0a, f0b, (u + 1) % kNsW, 0, true, same ? kcur : knext, same ? lim_cur : lim_next,
-                    same ? sl + kNsW : sl + kNsW - 12, u);
-          wait_lds();
-        }
+      for (int sl = 0; sl < 12; ++sl) {
+        const int qs = sl & 1, ks3 = sl % 3;              // stages of this slab
+        const int qn = (sl + 1) & 1, kn = (sl + 1) % 3;    // stages of the next slab
+        if (ABL & 2048) tstamp(0);
+        // step 0: (k-step 0, ray half 0); read B(k-step 0, half 1)
+        mfma_step(a0, b0, 0, [&](const int slot) {
+          if (!(ABL & 16) && slot < 4) b1[slot >> 1][slot & 1] = read_b(2 + (slot >> 1), 0, slot & 1, ks3);
+        });
+        wait_lds();
+        // step 1: (k-step 0, half 1); read A(k-step 1), B(k-step 1, half 0)
+        mfma_step(a0, b1, 1, [&](const int slot) {
+          if (!(ABL & 16) && slot < 4) a1[slot >> 1][slot & 1] = read_a(slot >> 1, 1, slot & 1, qs);
+          else if (!(ABL & 16) && slot < 8) b0[(slot - 4) >> 1][slot & 1] = read_b((slot - 4) >> 1, 1, slot & 1, ks3);
+        });
+        wait_lds();
+        // step 2: (k-step 1, half 0); read B(k-step 1, half 1) -- the last reads of this slab
+        mfma_step(a1, b0, 0, [&](const int slot) {
+          if (!(ABL & 16) && slot < 4) b1[slot >> 1][slot & 1] = read_b(2 + (slot >> 1), 1, slot & 1, ks3);
+        });
+        wait_lds();
+        // q(sl+1) was issued first in the previous batch: only that batch's 4 key pieces are younger.  After the barrier
+        // slab sl+1 is visible to every wave and the stages of slab sl are free.
+        if (ABL & 2048) tstamp(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ABL & 2048) tstamp(2);
+        if (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+        if (ABL & 2048) tstamp(3);
+        // step 3: (k-step 1, half 1); read A / B(half 0) of slab sl+1; issue q(sl+2) -> q stage qs, key(sl+3) -> key stage ks3
+        mfma_step(a1, b1, 1, [&](const int slot) {
+          if (!(ABL & 16) && slot < 4) a0[slot >> 1][slot & 1] = read_a(slot >> 1, 0, slot & 1, qn);
+          else if (!(ABL & 16) && slot < 8) b0[(slot - 4) >> 1][slot & 1] = read_b((slot - 4) >> 1, 0, slot & 1, kn);
+          if (slot < 4) issue_q((sl + 2) % 12, qs, slot);
+          else if (slot < 8) {
+            if (sl + 3 < 12) issue_k(kcur, lim_cur, sl + 3, ks3, slot - 4);
+            else issue_k(knext, lim_next, sl + 3 - 12, ks3, slot - 4);
+          }
+        });
+        wait_lds();
+        if (ABL & 2048) tstamp(4);
       }
 
       if (ABL & 2) {
@@ -896,7 +704,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
         if (sacc == 12345.678f) lg[lane] = sacc;
@@ -904,16 +712,19 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
         lim_cur = lim_next;
         continue;
       }
-      // ---- epilogue (see k_logits_f16): 16-byte stores, 1 KiB contiguous per wave instruction; per-lane running stats
+      // ---- epilogue.  Lane l holds token (l & 31) and, per accumulator register group rg, the four consecutive rays
+      // 8 rg + 4 (l >> 5) + {0..3} of its 32-ray block: one 16-byte store per group, 1 KiB contiguous per wave instruction.
+      // The constant undoes both power-of-two operand scales (exactly) and applies 1/sqrt 384.
       if (active) {
-        const float cf = (cq * load_uniform(A.kinv + tile)) * kInvSqrtD;
-        float* tb = lg + (int64_t)tile * (kT * kBN);
-        const bool ragged = lim_cur < kBN - 1;           // only the last ray tile of the scene
+        const int t128 = min(2 * tile + wn, n_tiles128 - 1);
+        const float cf = (cq * load_uniform(A.kinv + t128)) * kInvSqrtD;
+        float* tb = lg + (int64_t)(2 * tile + wn) * (kT * 128);
+        const bool ragged = lim_cur < kBNX - 1;           // only the last ray tile of the scene
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
           float mx = -INFINITY;
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
+          for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               float4 v;
@@ -925,29 +736,20 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
               acc[tm][tn][4 * rg + 1] = v.y;
               acc[tm][tn][4 * rg + 2] = v.z;
               acc[tm][tn][4 * rg + 3] = v.w;
-              if (!(ABL & 64)) {
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                f32x4 vv = {v.x, v.y, v.z, v.w};
-                if (ABL & 256) *reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = vv;
-                else __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256));
-              }
+              if (!(ABL & 64)) *reinterpret_cast<float4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = v;
               mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
             }
-          if (ABL & 128) {
-            m_run[tm] = fmaxf(m_run[tm], mx);
-            continue;
-          }
           const float mn = fmaxf(m_run[tm], mx);
           float sum[4] = {0.f, 0.f, 0.f, 0.f};
           if (!ragged) {
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
               for (int r = 0; r < 16; ++r) sum[r & 3] += __expf(acc[tm][tn][r] - mn);
           } else {
-            const int ray0 = wn * 64 + 4 * (lane >> 5);
+            const int ray0 = wn * 128 + 4 * (lane >> 5);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+            for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
               for (int r = 0; r < 16; ++r)
                 sum[r & 3] += (ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur) ? __expf(acc[tm][tn][r] - mn) : 0.f;
@@ -958,8 +760,16 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16w(LogitsF16Args A) {
       }
       kcur = knext;
       lim_cur = lim_next;
+      if (ABL & 2048) tstamp(5);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing prefetch
+#ifdef SIXDGS_ABLATION
+    if ((ABL & 2048) && lane == 0 && grp < 64) {
+#pragma unroll
+      for (int ph = 0; ph < 6; ++ph) atomicAdd(&g_dbg_cycles[wave][ph], t_acc[ph]);
+      if (wave == 0) atomicAdd(&g_dbg_cycles[0][7], 1ull);
+    }
+#endif
   }
   // merge the four partials of every token (2 ray halves of the lane layout x 2 waves wn) through the (now idle) ring
   __syncthreads();
@@ -1080,7 +890,7 @@ __global__ void __launch_bounds__(256) k_score_reduce(const float* __restrict__ 
   scores[(int64_t)bl * score_stride + j] = s;
 }
 
-// pass 2 on the blocked logits of k_logits_f16 ([tile][token group 8][ray quad 32][token 32][ray 4]): a wave owns a pair of
+// pass 2 on the blocked logits of k_logits_f16x ([tile][token group 8][ray quad 32][token 32][ray 4]): a wave owns a pair of
 // ray quads (8 rays): lanes 0..31 / 32..63 hold the 32 tokens of a group for quad 2p / 2p+1, every load instruction reads
 // 1 KiB contiguous, the 8 token groups accumulate in registers and one butterfly over 32 lanes finishes the column sums.
 __global__ void __launch_bounds__(256) k_score_reduce_blocked(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ stats,
@@ -1360,7 +1170,7 @@ struct ScorePlan {
 };
 ScorePlan score_plan(int64_t r, int batch, int topk) {
   ScorePlan p;
-  p.ldl = sdg_cdiv(r > 0 ? r : 1, 128) * 128;
+  p.ldl = sdg_cdiv(r > 0 ? r : 1, 256) * 256;   // whole 256-ray tiles (k_logits_f16x)
   p.n_tiles = (int)sdg_cdiv(r > 0 ? r : 1, kBN);
   p.tiles_per_group = (int)sdg_cdiv(p.n_tiles, 2048);
   p.n_groups = (int)sdg_cdiv(p.n_tiles, p.tiles_per_group);
@@ -1452,6 +1262,7 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
     float* sc = scores ? scores + (int64_t)b0 * r : sc_ws;
     const int64_t sc_stride = scores ? r : (int64_t)(p.per_image_scores / sizeof(float));
     if (r > 0) {
+      int n_groups_used = p.n_groups;
       LogitsArgs A = {q, d_n_tok, key, logits, partial, r, (int64_t)(p.per_image_logits / sizeof(float) / kT),
                       p.tiles_per_group, p.n_tiles, p.n_groups, b0};
       {
@@ -1467,37 +1278,31 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
                              (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes, qinv);
           LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)key_planes, qinv - 2 * b0, d_key_scale, logits,
                              partial, r, A.ldl, p.tiles_per_group, p.n_tiles, p.n_groups, b0, nb};
-          const char* kv = getenv("SIXDGS_F16_KERNEL");   // evaluation switch: w (default) | ns2 | ns4
-          if (!kv || kv[0] == 'w') {
-            auto kern = k_logits_f16w<0>;
-#ifdef SIXDGS_ABLATION
-            if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
-#define SDG_ABL_CASE(n) case n: kern = k_logits_f16w<n>; break;
-              switch (atoi(ab)) {
-                SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
-                SDG_ABL_CASE(18) SDG_ABL_CASE(10) SDG_ABL_CASE(3) SDG_ABL_CASE(64) SDG_ABL_CASE(128) SDG_ABL_CASE(192) SDG_ABL_CASE(256)
-                default: break;
-              }
-#undef SDG_ABL_CASE
+          // 256-ray tiles in groups: (groups x images) is a multiple of the CU count (equal-length runs, no partial last
+          // round) with runs of at least 16 tiles when the scene is large enough
+          const int n_tiles_x = (p.n_tiles + 1) / 2;
+          int n_groups_x = (2048 / nb) > 0 ? (2048 / nb) / 256 * 256 : 256;
+          if (n_groups_x < 256) n_groups_x = 256;
+          while (n_groups_x > 256 && n_tiles_x / n_groups_x < 16) n_groups_x -= 256;
+          if (n_groups_x > p.n_groups) n_groups_x = p.n_groups;
+          const int tpg_x = (int)sdg_cdiv(n_tiles_x, n_groups_x);
+          n_groups_used = (int)sdg_cdiv(n_tiles_x, tpg_x);
+          V.tiles_per_group = tpg_x;
+          V.n_tiles = n_tiles_x;
+          V.n_groups = n_groups_used;
+          auto kern = k_logits_f16x<0>;
+#ifdef SIXDGS_ABLATION   // timing experiments only (tools/ablate_logits.py builds a private copy of the library with it)
+          if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
+#define SDG_ABL_CASE(n) case n: kern = k_logits_f16x<n>; break;
+            switch (atoi(ab)) {
+              SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
+              SDG_ABL_CASE(64) SDG_ABL_CASE(2048)
+              default: break;
             }
-#endif
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_groups * nb)), dim3(512), 0, s, V);
-          } else {
-            const bool ns2 = kv[2] == '2';
-            auto kern = ns2 ? k_logits_f16<0, 2> : k_logits_f16<0, 4>;
-#ifdef SIXDGS_ABLATION
-            if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
-#define SDG_ABL_CASE(n) case n: kern = ns2 ? k_logits_f16<n, 2> : k_logits_f16<n, 4>; break;
-              switch (atoi(ab)) {
-                SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
-                SDG_ABL_CASE(18) SDG_ABL_CASE(10) SDG_ABL_CASE(3)
-                default: break;
-              }
 #undef SDG_ABL_CASE
-            }
-#endif
-            hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_groups * 2 * nb)), dim3(256), 0, s, V);
           }
+#endif
+          hipLaunchKernelGGL(kern, dim3((unsigned)(n_groups_used * nb)), dim3(512), 0, s, V);
         } else if (use_v2) {
           // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
           hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,
@@ -1531,7 +1336,7 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
           hipLaunchKernelGGL(k_logits<kMmaBf16x6>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
         }
       }
-      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, p.n_groups, stats);
+      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, n_groups_used, stats);
       if (use_f16)
         hipLaunchKernelGGL(k_score_reduce_blocked, dim3((unsigned)p.n_tiles, (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats, d_n_tok,
                            b0, r, sc, sc_stride);
@@ -1556,6 +1361,17 @@ int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const f
   return sixdgs_score_topk_ex(q, d_n_tok, nullptr, batch, key, nullptr, nullptr, r, topk, scores, idx, val, row_stats, ws, ws_bytes,
                               stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
+
+#ifdef SIXDGS_ABLATION
+int sixdgs_debug_cycles(unsigned long long* host64, int reset) {   // ablation builds only (tools/ablate_logits.py)
+  hipError_t e = hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_dbg_cycles), sizeof(unsigned long long) * 64);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[64] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_cycles), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops_total, double* bytes_total, int* launches) {
   SDG_CHECK_ARG(prof);
