@@ -73,10 +73,25 @@ class _Block(torch.nn.Module):
         return x + self.ls2(self.mlp(self.norm2(x)))
 
 
+class _PatchConv(torch.nn.Conv2d):
+    """Conv2d with kernel == stride (non-overlapping patches) evaluated as one GEMM over the unfolded patches.
+    MIOpen has no tuned fp32 solver for the 14x14 / stride-14 patch embedding and falls back to its naive kernel
+    (2.3 ms per call on MI355X, more than the rest of the ViT); same parameters and state_dict keys as the Conv2d."""
+
+    def forward(self, x):
+        p, q = self.kernel_size
+        if self.stride != (p, q) or self.padding != (0, 0) or self.dilation != (1, 1) or self.groups != 1 or x.shape[2] % p or x.shape[3] % q:
+            return super().forward(x)
+        b, c, h, w = x.shape
+        cols = x.reshape(b, c, h // p, p, w // q, q).permute(0, 2, 4, 1, 3, 5).reshape(b, (h // p) * (w // q), c * p * q)
+        y = F.linear(cols, self.weight.reshape(self.out_channels, -1), self.bias)
+        return y.transpose(1, 2).reshape(b, self.out_channels, h // p, w // q)
+
+
 class _PatchEmbed(torch.nn.Module):
     def __init__(self, dim, patch):
         super().__init__()
-        self.proj = torch.nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+        self.proj = _PatchConv(3, dim, kernel_size=patch, stride=patch)
 
     def forward(self, x):
         return self.proj(x).flatten(2).transpose(1, 2)
@@ -126,6 +141,9 @@ def create_backbone(type="dino", backbone: Optional[torch.nn.Module] = None, **k
     if backbone is None:
         try:
             backbone = torch.hub.load("facebookresearch/dinov2", "dinov2_vits14")
+            proj = getattr(getattr(backbone, "patch_embed", None), "proj", None)
+            if isinstance(proj, torch.nn.Conv2d):
+                proj.__class__ = _PatchConv          # same parameters, GEMM evaluation
         except Exception as e:  # offline: no network, no cache
             warnings.warn(f"DINOv2 weights unavailable ({e.__class__.__name__}); using a randomly initialised ViT-S/14")
             backbone = ViTS14()

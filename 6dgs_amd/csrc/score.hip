@@ -1268,9 +1268,11 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
       {
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
-        // operand bytes per ray: 1536 B fp32 key, or 2304 B of bf16 planes on the DMA-fed path
+        // operand bytes per ray: 1536 B fp32 key or 2304 B of bf16 planes per image; the fp16x3 kernel streams its 1536 B of
+        // fp16 planes once per LAUNCH (the images of a launch share every key tile through L2)
         SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r,
-                              (double)r * (nb * ((use_v2 && !use_f16) ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
+                              use_f16 ? (double)r * (kRowF + tok * 4.0)
+                                      : (double)r * (nb * (use_v2 ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
         if (use_f16) {
           // scaled fp16 planes of q (one power-of-two scale per 128-token half), then the fp16x3 kernel
           float* qinv = (float*)(qplanes + (size_t)bg * (p.per_image_qplanes - 256));

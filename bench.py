@@ -140,7 +140,8 @@ def main():
         "metric": "poses/sec", "value": round(value, 4), "unit": "poses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 results; contractions evaluated as 3-way bf16 split x 6 MFMA terms with fp32 accumulation (error <= fp32 MFMA chain)",
+        "arithmetic": ("fp32 results; q.K^T as 2 power-of-two-scaled fp16 planes x 3 MFMA terms, dense layers as 3 bf16 planes x 6 MFMA "
+                       "terms, fp32 accumulation (measured error <= that of the fp32 MFMA chain)"),
         "config": {
             "workload": (f"synthetic {args.gaussians}-Gaussian scene, "
                          + (f"iso-cell emission from every valid Gaussian x {args.rays_per_ellipsoid} rays" if args.mode == "full"
@@ -156,24 +157,25 @@ def main():
                           "ray_mlp_keys_tflops": round(k_fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None},
     }
     if rank == 0:
+        mode = ops.effective_mma_mode()
+        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3"}[mode]
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("rays") == R and tj.get("mode") == args.mode:
+                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"]:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0
-        mode = ops.effective_mma_mode()
         terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3}[mode]
         peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_BF16_MFMA_TFLOPS / terms
-        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3"}[mode]
         out["roofline"] = {
             "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
                                        "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
-                       ops.MMA_F16X3: "k_logits_f16: q.K^T with fp32 operands scaled by a power of two and split into 2 fp16 planes, 3 cross "
-                                      "terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
+                       ops.MMA_F16X3: "k_logits_f16x: q.K^T (256 tokens x 256 rays per tile) with fp32 operands scaled by a power of two and split "
+                                      "into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA rings, "
+                                      "online row stats, logits stored once",
                        ops.MMA_F32: "k_logits<f32>: q.K^T on v_mfma_f32_32x32x2_f32, online row stats, logits stored once"}[mode],
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),
