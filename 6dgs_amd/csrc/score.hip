@@ -1228,16 +1228,23 @@ int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes
   return 0;
 }
 
-int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
-                         const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* scores, int64_t* idx,
-                         float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
-                         int mma_mode) {
+}  // extern "C"
+
+namespace {
+// phase 0: the whole scorer.  Phases 1 / 2 split it at the row statistics for ray-sharded scoring: phase 1 leaves the
+// logits of ALL `batch` images in the workspace and returns the local statistics in row_stats; phase 2 takes the global
+// statistics from row_stats and finishes (column sums, top-k).  `planes`: the logits are in the blocked fp16x3 layout.
+int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
+               const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* scores, int64_t* idx, float* val,
+               float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
-  const bool use_f16 = key_planes != nullptr && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT);
-  SDG_CHECK_ARG(!use_f16 || d_key_scale != nullptr);
-  const bool use_v2 = key_planes != nullptr && mma_mode != SIXDGS_MMA_F32;
-  SDG_CHECK_ARG(q && d_n_tok && (key || use_v2 || r == 0) && idx && val && ws);
+  const bool f16_mode = mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT;
+  const bool use_f16 = (phase == 2 ? planes : key_planes != nullptr) && f16_mode;
+  SDG_CHECK_ARG(phase == 2 || !use_f16 || d_key_scale != nullptr);
+  const bool use_v2 = (phase == 2 ? planes : key_planes != nullptr) && mma_mode != SIXDGS_MMA_F32;
+  SDG_CHECK_ARG(d_n_tok && ws && (phase == 2 || (q && (key || use_v2 || r == 0))) && (phase == 1 || (idx && val)) &&
+                (phase == 0 || row_stats));
   SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
   SDG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)ws % 256) == 0);
   hipStream_t s = sdg_stream(stream);
@@ -1246,7 +1253,7 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
   // largest image group whose logits + top-k scratch fit the caller's workspace
   int64_t bg = batch > 65535 ? 65535 : batch;
   while (bg >= 1 && topk_plan(r, (int)bg, topk).bytes + (size_t)bg * per_image > ws_bytes) --bg;
-  if (bg < 1) return SIXDGS_E_WORKSPACE;
+  if (bg < 1 || (phase != 0 && bg < batch)) return SIXDGS_E_WORKSPACE;   // the split phases keep every image resident
   p.topk_bytes = topk_plan(r, (int)bg, topk).bytes;
   char* base = (char*)ws;
   char* topk_ws = base;
@@ -1265,7 +1272,7 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
       int n_groups_used = p.n_groups;
       LogitsArgs A = {q, d_n_tok, key, logits, partial, r, (int64_t)(p.per_image_logits / sizeof(float) / kT),
                       p.tiles_per_group, p.n_tiles, p.n_groups, b0};
-      {
+      if (phase != 2) {
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
         // operand bytes per ray: 1536 B fp32 key or 2304 B of bf16 planes per image; the fp16x3 kernel streams its 1536 B of
@@ -1338,7 +1345,19 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
           hipLaunchKernelGGL(k_logits<kMmaBf16x6>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
         }
       }
-      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, n_groups_used, stats);
+      if (phase != 2) hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, n_groups_used, stats);
+      if (phase == 2) {        // the caller's global statistics replace the local ones
+        hipError_t e = hipMemcpyAsync(stats, row_stats + (int64_t)b0 * kT * 2, (size_t)nb * kT * 2 * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+      }
+      if (phase == 1) {
+        hipError_t e = hipMemcpyAsync(row_stats + (int64_t)b0 * kT * 2, stats, (size_t)nb * kT * 2 * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+        SDG_LAUNCH_OK();
+        continue;
+      }
       if (use_f16)
         hipLaunchKernelGGL(k_score_reduce_blocked, dim3((unsigned)p.n_tiles, (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats, d_n_tok,
                            b0, r, sc, sc_stride);
@@ -1346,16 +1365,41 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
         hipLaunchKernelGGL(k_score_reduce, dim3((unsigned)sdg_cdiv(r, 256), (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
                            d_n_tok, b0, r, sc, sc_stride);
       SDG_LAUNCH_OK();
-      if (row_stats) {
+      if (row_stats && phase == 0) {
         hipError_t e = hipMemcpyAsync(row_stats + (int64_t)b0 * kT * 2, stats, (size_t)nb * kT * 2 * sizeof(float),
                                       hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return (int)e;
       }
     }
+    if (phase == 1) continue;
     int st = run_topk(sc, sc_stride, r, nb, topk, idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, topk_ws, s);
     if (st) return st;
   }
   return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
+                         const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* scores, int64_t* idx,
+                         float* val, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof,
+                         int mma_mode) {
+  return score_impl(0, key_planes != nullptr, q, d_n_tok, h_n_tok, batch, key, key_planes, d_key_scale, r, topk, scores, idx, val,
+                    row_stats, ws, ws_bytes, stream, prof, mma_mode);
+}
+
+int sixdgs_score_pass1(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
+                       const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* row_stats, void* ws,
+                       size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
+  return score_impl(1, key_planes != nullptr, q, d_n_tok, h_n_tok, batch, key, key_planes, d_key_scale, r, topk, nullptr, nullptr,
+                    nullptr, row_stats, ws, ws_bytes, stream, prof, mma_mode);
+}
+
+int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch, int used_planes, int64_t r, int topk, float* scores,
+                       int64_t* idx, float* val, void* ws, size_t ws_bytes, sixdgs_stream_t stream, int mma_mode) {
+  return score_impl(2, used_planes != 0, nullptr, d_n_tok, nullptr, batch, nullptr, nullptr, nullptr, r, topk, scores, idx, val,
+                    const_cast<float*>(row_stats), ws, ws_bytes, stream, nullptr, mma_mode);
 }
 
 int sixdgs_score_topk(const float* q, const int32_t* d_n_tok, int batch, const float* key, int64_t r, int topk, float* scores,

@@ -8,6 +8,12 @@ across ranks with NO collective on the data path:
   3. images are split into contiguous blocks, one per rank;
   4. rank 0 gathers c2w[B,4,4] (+ status) once per batch -- a few hundred bytes per image.
 The helpers are plain tensor plumbing and also run on CPU tensors with the gloo backend (CI tests).
+
+Ray sharding (SURVEY 8(e) fallback, `score_topk_ray_sharded`): when the key cache of a scene does not fit one GPU
+(2 M Gaussians x 256 rays = 512 M rays = 786 GB of key planes) or a single image must be scored by several GPUs, every
+rank keeps a contiguous slice of the rays.  The softmax runs over all rays, so the scorer is cut at the row statistics:
+two all-reduces of [B,256] floats (max, then the rescaled sum of exponentials) between the two passes and one all-gather
+of the per-rank top-k candidates -- a few KB per image, latency-bound, the only collectives on a data path in this build.
 """
 from __future__ import annotations
 
@@ -123,3 +129,68 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# ray-sharded scoring
+# ---------------------------------------------------------------------------------------------
+def _collective_device(t: torch.Tensor) -> torch.Tensor:
+    """gloo moves host memory: tiny tensors take the detour through the CPU; nccl (RCCL) reduces device tensors in place."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
+def merge_row_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
+    """Local (max, sumexp) [B,T,2] of every rank's ray slice -> the statistics over all rays, identical on every rank:
+    M = max_g m_g;  S = sum_g s_g * exp(m_g - M).  Rows without rays anywhere stay (-inf, 0)."""
+    if not is_dist():
+        return stats
+    dev = stats.device
+    m = _collective_device(stats[..., 0].contiguous())
+    sl = _collective_device(stats[..., 1].contiguous())
+    mg = m.clone()
+    dist.all_reduce(mg, op=dist.ReduceOp.MAX, group=group)
+    scale = torch.where(torch.isinf(m) & (m < 0), torch.zeros_like(m), torch.exp(m - mg))
+    sg = sl * scale
+    dist.all_reduce(sg, op=dist.ReduceOp.SUM, group=group)
+    return torch.stack([mg, sg], dim=-1).to(dev)
+
+
+def merge_topk(idx_local: torch.Tensor, val: torch.Tensor, ray_offset: int, k: int, group=None):
+    """Per-rank top-k candidates (indices local to the rank's ray slice, -1 / NaN padded) -> the global top-k on every
+    rank, ordered like the single-GPU kernel: value descending, ties by the lower global ray index."""
+    gidx = torch.where(idx_local >= 0, idx_local + int(ray_offset), idx_local)
+    if is_dist():
+        world = dist.get_world_size(group)
+        dev = idx_local.device
+        gi, gv = _collective_device(gidx.contiguous()), _collective_device(val.contiguous())
+        bi = [torch.empty_like(gi) for _ in range(world)]
+        bv = [torch.empty_like(gv) for _ in range(world)]
+        dist.all_gather(bi, gi, group=group)
+        dist.all_gather(bv, gv, group=group)
+        gidx, val = torch.cat(bi, dim=1).to(dev), torch.cat(bv, dim=1).to(dev)
+    pad = gidx < 0
+    key = torch.where(pad, torch.full_like(val, -float("inf")), val)
+    big = torch.iinfo(torch.int64).max
+    order = torch.argsort(torch.where(pad, torch.full_like(gidx, big), gidx), dim=1, stable=True)      # index ascending ...
+    key, gidx, val = key.gather(1, order), gidx.gather(1, order), val.gather(1, order)
+    order = torch.argsort(key, dim=1, descending=True, stable=True)[:, :k]                            # ... then value descending, stable
+    return gidx.gather(1, order), val.gather(1, order)
+
+
+def score_topk_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], ray_offset: int, topk: int = 100,
+                           key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None, want_scores: bool = False,
+                           workspace: Optional[torch.Tensor] = None, group=None):
+    """Exact scorer over a ray set that is split across the ranks of `group`; this rank holds rays
+    [ray_offset, ray_offset + r_local).  Returns (global idx [B,k], val [B,k], local scores [B,r_local] | None), the first two
+    identical on every rank and equal to the single-GPU result up to the rounding of the sum of exponentials."""
+    from . import ops
+
+    r_local = key.shape[0] if key is not None else key_planes.shape[0]
+    b = q.shape[0]
+    if workspace is None:
+        workspace = torch.empty(ops.score_topk_workspace_bytes(r_local, b, topk), dtype=torch.uint8, device=q.device)
+    local = ops.score_pass1(q, n_tok, key, workspace, topk, key_planes=key_planes, key_scale=key_scale)
+    glob = merge_row_stats(local, group)
+    idx, val, scores = ops.score_pass2(glob, n_tok, r_local, workspace, topk, used_planes=key_planes is not None, want_scores=want_scores)
+    gidx, gval = merge_topk(idx, val, ray_offset, topk, group)
+    return gidx, gval, scores

@@ -364,6 +364,35 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
     return idx, val, scores, stats
 
 
+def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], workspace: torch.Tensor, topk: int = 100,
+                key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """First half of the ray-sharded scorer (include/sixdgs.h: sixdgs_score_pass1): logits of this shard for all images
+    stay in `workspace` (score_topk_workspace_bytes(r, batch, topk) bytes); returns the shard's row statistics [B,256,2]."""
+    q = _f32(q)
+    key = _f32(key) if key is not None else None
+    _need_gpu(q, key, n_tok, key_planes, workspace)
+    r = key.shape[0] if key is not None else key_planes.shape[0]
+    b = q.shape[0]
+    stats = torch.empty(b, MAX_TOKENS, 2, device=q.device)
+    check(_lib.load().sixdgs_score_pass1(_p(q), _p(n_tok), None, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(stats),
+                                         _p(workspace), workspace.numel(), _stream(), None, _mma_mode), "score_pass1")
+    return stats
+
+
+def score_pass2(stats: torch.Tensor, n_tok: torch.Tensor, r: int, workspace: torch.Tensor, topk: int = 100, used_planes: bool = True,
+                want_scores: bool = True):
+    """Second half: global row statistics [B,256,2] -> (local idx [B,k], val [B,k], scores [B,r] | None) of this shard."""
+    stats = _f32(stats)
+    _need_gpu(stats, n_tok, workspace)
+    b, dev = stats.shape[0], stats.device
+    idx = torch.empty(b, topk, dtype=torch.int64, device=dev)
+    val = torch.empty(b, topk, device=dev)
+    scores = torch.empty(b, r, device=dev) if want_scores else None
+    check(_lib.load().sixdgs_score_pass2(_p(stats), _p(n_tok), b, 1 if used_planes else 0, int(r), int(topk), _p(scores), _p(idx), _p(val),
+                                         _p(workspace), workspace.numel(), _stream(), _mma_mode), "score_pass2")
+    return idx, val, scores
+
+
 def topk(scores: torch.Tensor, k: int = 100):
     scores = _f32(scores)
     _need_gpu(scores)

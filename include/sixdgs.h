@@ -229,6 +229,20 @@ int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* 
                          int batch, const float* key, const void* key_planes, const float* d_key_scale, int64_t r, int topk,
                          float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,
                          sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
+
+/* Ray-sharded scoring (SURVEY 8(e) fallback: the key cache of a scene is split across GPUs, or one image must be scored by
+ * several).  The softmax runs over ALL rays, so the scorer is cut at the row statistics:
+ *   pass 1  logits of this shard's rays for ALL `batch` images stay in the workspace (SIXDGS_E_WORKSPACE if they do not
+ *           fit: sixdgs_score_topk_workspace_bytes(r, batch, topk)); row_stats[B,256,2] receives the shard's (max, sumexp);
+ *   caller  combines the shards: M = max over shards, S = sum over shards of s * exp(m - M)  (two tiny all-reduces);
+ *   pass 2  takes the global statistics, writes this shard's scores and its local top-k (indices local to the shard);
+ *           the global top-k is the (value desc, global index asc) merge of the shards' candidates.
+ * Same r, batch, topk, workspace and mma_mode in both passes; used_planes = pass 1 ran on key planes. */
+int sixdgs_score_pass1(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const float* key,
+                       const void* key_planes, const float* d_key_scale, int64_t r, int topk, float* row_stats, void* ws,
+                       size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
+int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch, int used_planes, int64_t r, int topk,
+                       float* scores, int64_t* idx, float* val, void* ws, size_t ws_bytes, sixdgs_stream_t stream, int mma_mode);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

@@ -79,3 +79,69 @@ def test_two_rank_gloo_pipeline_plumbing():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker_ray_shard(rank, world, port, q):
+    """The collectives of the ray-sharded scorer on CPU tensors: statistics merge and candidate merge."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        dd = importlib.import_module("6dgs_amd.distributed")
+        dd.init_from_env("gloo")
+        rng = np.random.default_rng(5)
+        B, T, R, K = 3, 256, 1000, 100
+        logits = (rng.standard_normal((B, T, R)) * 6).astype(np.float32)
+        logits[1, 40:] = -np.inf                     # image 1 has 40 tokens: the other rows never see a ray
+        lo, hi = dd.shard_range(R, rank, world)
+        loc = logits[:, :, lo:hi].astype(np.float64)
+        m = loc.max(axis=2)
+        with np.errstate(invalid="ignore"):
+            sl = np.where(np.isinf(m), 0.0, np.exp(loc - np.where(np.isinf(m), 0.0, m)[..., None]).sum(axis=2))
+        stats = torch.from_numpy(np.stack([m, sl], axis=-1).astype(np.float32))
+        g = dd.merge_row_stats(stats).numpy().astype(np.float64)
+        M = logits.astype(np.float64).max(axis=2)
+        with np.errstate(invalid="ignore"):
+            S = np.where(np.isinf(M), 0.0, np.exp(logits.astype(np.float64) - np.where(np.isinf(M), 0.0, M)[..., None]).sum(axis=2))
+        assert np.array_equal(g[..., 0], M.astype(np.float32).astype(np.float64))
+        assert np.allclose(g[..., 1], S, rtol=1e-6, atol=0)
+        # candidates: value ties across ranks resolve to the lower global index; short shards pad with (-1, NaN)
+        scores = rng.integers(0, 50, size=(B, R)).astype(np.float32)          # heavy ties
+        sc_loc = scores[:, lo:hi]
+        order = np.lexsort((np.broadcast_to(np.arange(hi - lo), sc_loc.shape), -sc_loc), axis=1)[:, :K]
+        idx = torch.from_numpy(order.astype(np.int64))
+        val = torch.from_numpy(np.take_along_axis(sc_loc, order, axis=1))
+        if rank == 1:                                                          # pretend this shard has only 7 rays for image 2
+            idx[2, 7:] = -1
+            val[2, 7:] = float("nan")
+        gi, gv = dd.merge_topk(idx, val, lo, K)
+        ref = scores.copy()
+        lo1, hi1 = dd.shard_range(R, 1, world)
+        keep1 = order if rank == 1 else np.lexsort((np.broadcast_to(np.arange(hi1 - lo1), (B, hi1 - lo1)), -scores[:, lo1:hi1]), axis=1)[:, :K]
+        mask = np.ones(R, bool)
+        mask[lo1:hi1] = False
+        mask[lo1 + keep1[2, :7]] = True
+        ref[2, ~mask] = -np.inf
+        ro = np.lexsort((np.broadcast_to(np.arange(R), ref.shape), -ref), axis=1)[:, :K]
+        assert np.array_equal(gi.numpy(), ro), (gi[2, :12], ro[2, :12])
+        assert np.array_equal(gv.numpy(), np.take_along_axis(ref, ro, axis=1))
+        dd.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+        raise e
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_ray_sharded_merges():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ray_shard, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -1,0 +1,55 @@
+"""Ray-sharded scoring (SURVEY 8(e) fallback): two ranks, each holding half of the rays, reproduce the single-GPU scorer
+(global top-100 identical, scores within the rounding of the sum of exponentials).  The ranks share the one GPU of the
+test box and talk over gloo; tools/ray_shard_check.py runs unchanged over RCCL on a multi-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("mode,port", [("f16x3", 29551), ("f32", 29552)])
+def test_two_ranks_ray_sharded_scorer_matches_single_gpu(mode, port):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    p = subprocess.run([sys.executable, "-W", "ignore", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "tools/ray_shard_check.py", "--backend", "gloo",
+                        "--device", "0", "--mode", mode, "--rays", "20037"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=380)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["ok"], d
+    assert [r["rays"] for r in d["ranks"]] == [[0, 10112], [10112, 20037]]
+
+
+def test_single_process_split_passes_equal_the_fused_scorer():
+    """pass 1 + pass 2 with the statistics handed straight back are the fused scorer, bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    ops = importlib.import_module("6dgs_amd.ops")
+    rng = np.random.default_rng(3)
+    key = torch.from_numpy(rng.standard_normal((5000, 384)).astype(np.float32)).cuda()
+    q = torch.from_numpy(rng.standard_normal((2, 256, 384)).astype(np.float32)).cuda()
+    n_tok = torch.tensor([256, 99], dtype=torch.int32, device="cuda")
+    q[1, 99:] = 0
+    pl, sc = ops.split_planes_f16(key)
+    idx0, val0, s0, st0 = ops.score_topk(q, n_tok, None, 100, want_stats=True, key_planes=pl, key_scale=sc)
+    ws = torch.empty(ops.score_topk_workspace_bytes(5000, 2, 100), dtype=torch.uint8, device="cuda")
+    st = ops.score_pass1(q, n_tok, None, ws, 100, key_planes=pl, key_scale=sc)
+    assert torch.equal(st, st0)
+    idx, val, s = ops.score_pass2(st, n_tok, 5000, ws, 100, used_planes=True)
+    assert torch.equal(idx, idx0) and torch.equal(val, val0) and torch.equal(s, s0)
+    small = torch.empty(ops.score_topk_workspace_bytes(5000, 1, 100), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):                      # both images must stay resident between the passes
+        ops.score_pass1(q, n_tok, None, small, 100, key_planes=pl, key_scale=sc)

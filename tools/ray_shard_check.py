@@ -1,0 +1,71 @@
+"""Ray-sharded scorer check (run under torch.distributed.run, any world size; tests/test_gpu_ray_sharded.py launches it
+with two gloo ranks on one GPU; on a multi-GPU node run it over RCCL: --backend nccl).
+Every rank builds the SAME synthetic keys and query, scores its contiguous ray slice through
+distributed.score_topk_ray_sharded and compares with the single-GPU scorer over all rays."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default=None)
+    ap.add_argument("--device", type=int, default=None, help="force this device on every rank (single-GPU test boxes)")
+    ap.add_argument("--rays", type=int, default=20_000)
+    ap.add_argument("--mode", default="f16x3")
+    a = ap.parse_args()
+    dd = importlib.import_module("6dgs_amd.distributed")
+    ops = importlib.import_module("6dgs_amd.ops")
+    syn = importlib.import_module("6dgs_amd.synthetic")
+    rank, world, local = dd.init_from_env(a.backend, set_device=a.device is None)
+    dev = torch.device("cuda", a.device if a.device is not None else local)
+    torch.cuda.set_device(dev)
+    ops.set_mma_mode({"f16x3": ops.MMA_F16X3, "bf16x6": ops.MMA_BF16X6, "f32": ops.MMA_F32}[a.mode])
+    rng = np.random.default_rng(11)
+    R = a.rays
+    key = torch.from_numpy((rng.standard_normal((R, 384)) * 0.7).astype(np.float32)).to(dev)
+    q = torch.zeros(3, 256, 384, device=dev)
+    n = [256, 137, 1]
+    for i, t in enumerate(n):
+        q[i, :t] = torch.from_numpy((rng.standard_normal((t, 384)) * 1.5).astype(np.float32)).to(dev)
+    n_tok = torch.tensor(n, dtype=torch.int32, device=dev)
+
+    def planes_of(k):
+        if a.mode == "f16x3":
+            return ops.split_planes_f16(k)
+        return (ops.split_planes(k), None) if a.mode == "bf16x6" else (None, None)
+
+    # single-GPU result over all rays
+    pl, sc = planes_of(key)
+    idx0, val0, s0, _ = ops.score_topk(q, n_tok, key, 100, key_planes=pl, key_scale=sc)
+    # this rank's slice (slices start at multiples of 128 rays so that the fp16 scale tiles coincide with the full run)
+    per = -(-R // world)
+    per = -(-per // 128) * 128
+    lo, hi = min(rank * per, R), min((rank + 1) * per, R)
+    kl = key[lo:hi].contiguous()
+    pl_l, sc_l = planes_of(kl)
+    gidx, gval, s_loc = dd.score_topk_ray_sharded(q, n_tok, kl, lo, 100, key_planes=pl_l, key_scale=sc_l, want_scores=True)
+    torch.cuda.synchronize()
+    s0n, sl = s0[:, lo:hi].cpu().numpy(), s_loc.cpu().numpy()
+    rel = float(np.abs(sl - s0n).max() / np.abs(s0n).max()) if hi > lo else 0.0
+    same_idx = bool(torch.equal(gidx, idx0))
+    val_rel = float(((gval - val0).abs().max() / val0.abs().max()).item())
+    out = {"rank": rank, "world": world, "rays": [lo, hi], "scores_rel_err": rel, "topk_idx_equal": same_idx, "topk_val_rel_err": val_rel}
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, out) if world > 1 else gathered.__setitem__(0, out)
+    if rank == 0:
+        print(json.dumps({"ranks": gathered, "ok": all(g["topk_idx_equal"] and g["scores_rel_err"] < 2e-6 and g["topk_val_rel_err"] < 2e-6
+                                                          for g in gathered)}), flush=True)
+    dd.barrier()
+
+
+if __name__ == "__main__":
+    main()
