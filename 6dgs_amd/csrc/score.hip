@@ -1287,11 +1287,11 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
                              (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes, qinv);
           LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)key_planes, qinv - 2 * b0, d_key_scale, logits,
                              partial, r, A.ldl, p.tiles_per_group, p.n_tiles, p.n_groups, b0, nb};
-          // 256-ray tiles in groups: (groups x images) is a multiple of the CU count (equal-length runs, no partial last
-          // round) with runs of at least 16 tiles when the scene is large enough
+          // 256-ray tiles in groups: the group count is a multiple of the CU count (equal-length runs, no partial last
+          // round for any number of images) and does NOT depend on the batch, so an image scores to the same bits alone
+          // or inside a batch; runs of at least 16 tiles when the scene is large enough
           const int n_tiles_x = (p.n_tiles + 1) / 2;
-          int n_groups_x = (2048 / nb) > 0 ? (2048 / nb) / 256 * 256 : 256;
-          if (n_groups_x < 256) n_groups_x = 256;
+          int n_groups_x = 1024;
           while (n_groups_x > 256 && n_tiles_x / n_groups_x < 16) n_groups_x -= 256;
           if (n_groups_x > p.n_groups) n_groups_x = p.n_groups;
           const int tpg_x = (int)sdg_cdiv(n_tiles_x, n_groups_x);
