@@ -38,6 +38,8 @@ SIGNATURES = {
     "sixdgs_mask_degraded": (i32, [vp, i64, i32, vp, vp]),
     "sixdgs_sym_eig_3x3": (i32, [vp, i64, vp, vp, vp]),
     "sixdgs_normals_knn": (i32, [vp, i64, vp, i64, i32, vp, vp, vp]),
+    "sixdgs_normals_knn_grid_workspace_bytes": (sz, [i64]),
+    "sixdgs_normals_knn_grid": (i32, [vp, i64, vp, i64, i32, vp, vp, vp, sz, vp]),
     "sixdgs_emit_quadricell_count": (i32, [vp, vp, i32, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp]),
     "sixdgs_emit_quadricell_write": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, vp, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sixdgs_quadricell_cell_counts": (i32, [vp, i64, i32, vp, vp, vp, vp]),

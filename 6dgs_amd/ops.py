@@ -85,14 +85,29 @@ def sym_eig_3x3(mats: torch.Tensor, eigenvectors: bool = True):
     return vals.reshape(*shape, 3), (vecs.reshape(*shape, 3, 3) if eigenvectors else None)
 
 
-def normals_knn(query: torch.Tensor, cloud: torch.Tensor, k: int = 20, return_knn: bool = False):
+KNN_GRID_FROM = 16384     # clouds at least this large take the grid search (identical results, O(E) instead of O(E^2))
+
+
+def normals_knn(query: torch.Tensor, cloud: torch.Tensor, k: int = 20, return_knn: bool = False, method: str = "auto"):
+    """a4.  method: "brute" (the reference's exhaustive search), "grid" (uniform-grid search, same neighbour lists and
+    normals bit for bit) or "auto" (grid from KNN_GRID_FROM points)."""
+    same = query is cloud
     query, cloud = _f32(query), _f32(cloud)
+    if same:
+        query = cloud                      # keeps the pointer identity the grid kernel uses to walk the queries in cell order
     _need_gpu(query, cloud)
-    nq = query.shape[0]
+    lib = _lib.load()
+    nq, e = query.shape[0], cloud.shape[0]
     out = torch.empty(nq, 3, device=query.device)
     knn = torch.empty(nq, k, dtype=torch.int64, device=query.device) if return_knn else None
-    check(_lib.load().sixdgs_normals_knn(_p(query), nq, _p(cloud), cloud.shape[0], int(k), _p(out), _p(knn), _stream()),
-          "normals_knn")
+    if method not in ("auto", "brute", "grid"):
+        raise ValueError(method)
+    if method == "grid" or (method == "auto" and e >= KNN_GRID_FROM):
+        ws = torch.empty(lib.sixdgs_normals_knn_grid_workspace_bytes(e), dtype=torch.uint8, device=query.device)
+        check(lib.sixdgs_normals_knn_grid(_p(query), nq, _p(cloud), e, int(k), _p(out), _p(knn), _p(ws), ws.numel(), _stream()),
+              "normals_knn_grid")
+    else:
+        check(lib.sixdgs_normals_knn(_p(query), nq, _p(cloud), e, int(k), _p(out), _p(knn), _stream()), "normals_knn")
     return (out, knn) if return_knn else out
 
 

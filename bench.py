@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=800)
     ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f32"], default="default",
                     help="matrix-core scheme of the logits kernel (default = the library's default mode)")
-    ap.add_argument("--in-flight", type=int, default=2, help="images whose [256,R] logits are resident at once")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="images whose [256,R] logits are resident at once (0 = as many of the batch as fit in 60 %% of the free HBM)")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
@@ -105,8 +106,15 @@ def main():
     torch.cuda.synchronize()
     t_keys = time.time() - t0
     k_ms, k_fl, _, _ = kprof.collect()
-    # images whose [256, R] logits are resident at once: --in-flight, or the whole batch when that fits in 48 GB
-    inflight = args.batch if ops.score_topk_workspace_bytes(R, args.batch, 100) <= 48 * 2**30 else min(args.in_flight, args.batch)
+    # images whose [256, R] logits are resident at once (they share every key tile through L2): --in-flight, or as many
+    # of the batch as fit in 60 % of the free HBM (1 KB per ray and image: 4 x 32.8 GB at R = 32 M next to 49 GB of keys)
+    if args.in_flight > 0:
+        inflight = min(args.in_flight, args.batch)
+    else:
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        inflight = args.batch
+        while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100) > 0.6 * free_b:
+            inflight -= 1
     ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100), dtype=torch.uint8, device=dev)
     t_setup = time.time() - t_setup
 
@@ -148,7 +156,7 @@ def main():
                             else "reference-mode quadricell emission from 1000 sampled ellipsoids")
                          + f" (R={R} rays), {args.image_size}x{args.image_size} uint8 queries, 256 tokens x 384, top-100, "
                          f"{args.batch} images/GPU/step; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
-            "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch,
+            "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch, "images_per_logits_launch": inflight,
             "parallelism": f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)",
         },
         "errors_vs_synthetic_gt": {"mean_translation": float(sol["errors"][:, 0].mean()), "mean_angular_deg": float(sol["errors"][:, 1].mean()),
@@ -163,7 +171,7 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"]:
+                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

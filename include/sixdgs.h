@@ -94,6 +94,11 @@ int sixdgs_sym_eig_3x3(const float* mats /*[n,3,3]*/, int64_t n, float* vals /*[
  * indices sorted by distance.  k <= 32. */
 int sixdgs_normals_knn(const float* query /*[nq,3]*/, int64_t nq, const float* cloud /*[E,3]*/, int64_t e, int k,
                        float* normals /*[nq,3]*/, int64_t* knn /*[nq,k] or NULL*/, sixdgs_stream_t stream);
+/* The same result (neighbour lists and normals bit for bit) through a uniform grid: O(E) instead of O(E^2), for
+ * full-scene emission (the reference only ever runs a4 on 1000 ellipsoids).  Workspace: counting-sort buffers. */
+size_t sixdgs_normals_knn_grid_workspace_bytes(int64_t e);
+int sixdgs_normals_knn_grid(const float* query, int64_t nq, const float* cloud, int64_t e, int k, float* normals, int64_t* knn,
+                            void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 
 /* a1+a6+a7+a10, quadricell emitter (quadricell.py:191-386 with direction_mode="isocell", SH colour
  * sampling.py:116-124,225-251).  Ellipsoid j of the emission set is Gaussian sel[j] (sel == NULL:

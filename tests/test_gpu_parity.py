@@ -72,6 +72,33 @@ def test_a4_normals_knn(ops, oracle, golden):
     assert np.abs(N(n)[same] - g["normals"][same]).max() < 5e-4
 
 
+@pytest.mark.parametrize("kind", ["gauss", "clustered", "duplicates", "plane", "tiny"])
+def test_a4_grid_knn_is_the_brute_force_search(ops, kind):
+    """The uniform-grid search returns the brute-force neighbour lists (order included) and normals bit for bit."""
+    rng = np.random.default_rng(4)
+    n = 60_000
+    if kind == "gauss":
+        c = rng.standard_normal((n, 3))
+    elif kind == "clustered":                         # dense blobs + far outliers: many empty cells, deep shells
+        c = np.concatenate([rng.standard_normal((n - 200, 3)) * 0.01 + rng.integers(0, 3, (n - 200, 1)), rng.standard_normal((200, 3)) * 50])
+    elif kind == "duplicates":                        # exact distance ties -> lowest index first
+        c = np.repeat(rng.standard_normal((n // 4, 3)), 4, axis=0)
+    elif kind == "plane":                             # degenerate extent along one axis
+        c = rng.standard_normal((n, 3)) * np.array([1.0, 1.0, 0.0])
+    else:
+        n = 30
+        c = rng.standard_normal((n, 3))
+    c = G(c.astype(np.float32))
+    nb, kb = ops.normals_knn(c, c, 20, return_knn=True, method="brute")
+    ng, kg = ops.normals_knn(c, c, 20, return_knn=True, method="grid")
+    assert torch.equal(kb, kg)
+    assert torch.equal(torch.nan_to_num(nb), torch.nan_to_num(ng)) and torch.equal(torch.isnan(nb), torch.isnan(ng))
+    q = G((rng.standard_normal((777, 3)) * 1.5).astype(np.float32))       # queries that are not cloud points, some outside the box
+    nb, kb = ops.normals_knn(q, c, 20, return_knn=True, method="brute")
+    ng, kg = ops.normals_knn(q, c, 20, return_knn=True, method="grid")
+    assert torch.equal(kb, kg) and torch.equal(torch.nan_to_num(nb), torch.nan_to_num(ng))
+
+
 def test_a4_normals_knn_chunked_queries(ops, oracle):
     rng = np.random.default_rng(3)
     cloud = rng.standard_normal((2500, 3)).astype(np.float32)
