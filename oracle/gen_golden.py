@@ -489,13 +489,41 @@ def g7(m):
     save("g7_e2e", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g8: a24 with loss_fn (test.py:108-142): the reference loop with the stand-in callable of oracle/standin_loss.py
+# --------------------------------------------------------------------------------------
+def g8(m):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from standin_loss import line_distance_loss
+    g7d = np.load(os.path.join(OUT, "g7_e2e.npz"))
+    sd_np = syn.make_scorer_state_dict(0, with_cnn=True)
+    idm = _load_scorer(m, sd_np)
+    CameraInfo = m["scene_structure"].CameraInfo
+    cams_np = syn.make_cameras(3, 7, width=96, height=96, rgba=False) + syn.make_cameras(1, 8, width=80, height=80, rgba=True)
+    cams = [CameraInfo(**c) for c in cams_np]
+    rays_ori, rays_dir, rays_rgb = T(g7d["n3000_p50_ori"]), T(g7d["n3000_p50_dir"]), T(g7d["n3000_p50_rgb"])
+    with torch.no_grad():
+        idm.attention.q_proj.weight.mul_(40.0)
+    results, te, ae, ls, rc = m["test"].test_pose_estimation(
+        cams, idm, rays_ori, rays_dir, rays_rgb, torch.tensor([0.0, 1.0, 0.0]), loss_fn=line_distance_loss)
+    out = {"n": np.int64(len(results)), "mean_terr": np.float64(te), "mean_aerr": np.float64(ae), "mean_loss": np.float64(ls),
+           "mean_recall": np.float64(rc)}
+    for i, r in enumerate(results):
+        out[f"r{i}_pred_c2w"] = np.array(r["pred_c2w"], np.float32)
+        out[f"r{i}_loss"] = np.float32(r["loss"])
+        out[f"r{i}_scores_loss"] = np.float64(r["scores_loss"])
+        out[f"r{i}_recall"] = np.float64(r["recall"])
+    print("  g8: terr %.3e aerr %.3e loss %.3e recall %.3f" % (te, ae, ls, rc))
+    save("g8_lossfn", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:

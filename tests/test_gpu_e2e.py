@@ -130,6 +130,30 @@ def test_a24_test_pose_estimation(pkg, e2e):
     assert abs(ae - float(g["e2e_mean_aerr"])) < 1e-2
 
 
+def test_a24_loss_fn_branch(pkg, e2e, golden):
+    """test.py:108-142: with a loss_fn the loop scores the prediction (scores_loss, recall -- including the reference's quirk of
+    comparing positions 0..99 with ray ids) and then solves the pose from the top-100 of the TARGET scores.  The reference ran
+    with the stand-in callable of oracle/standin_loss.py (tests/golden/g8_lossfn.npz); the build's loop runs with the same one."""
+    from oracle.standin_loss import line_distance_loss
+    g, idm, cams = e2e
+    g8 = golden("g8_lossfn")
+    n = int(g8["n"])
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    toks = [G(g[f"e2e{i}_tokens"]) for i in range(n)]
+    ups = torch.stack([G(g[f"e2e{i}_up"]) for i in range(n)])
+    res, te, ae, ls, rc = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 1.0, 0.0]), loss_fn=line_distance_loss,
+                                                   token_override=toks, up_override=ups, verbose=False, batch_size=3)
+    assert len(res) == n
+    for i, r in enumerate(res):
+        ref = g8[f"r{i}_pred_c2w"]
+        assert np.abs(np.array(r["pred_c2w"], np.float32) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), i
+        assert abs(r["scores_loss"] - float(g8[f"r{i}_scores_loss"])) <= 1e-4 * abs(float(g8[f"r{i}_scores_loss"]))
+        assert r["recall"] == float(g8[f"r{i}_recall"])
+        assert abs(r["loss"] - float(g8[f"r{i}_loss"])) < 1e-5
+    assert abs(te - float(g8["mean_terr"])) < 1e-4 and abs(ae - float(g8["mean_aerr"])) < 1e-2
+    assert abs(ls - float(g8["mean_loss"])) <= 1e-4 * abs(float(g8["mean_loss"])) and rc == float(g8["mean_recall"])
+
+
 def test_scores_match_reference_through_module(pkg, e2e):
     g, idm, _ = e2e
     ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
