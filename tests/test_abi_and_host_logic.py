@@ -119,3 +119,51 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_ply_ingestion_follows_the_reference_layout(tmp_path):
+    """A file written the way gaussian_model.py:298-334 writes it (independent numpy writer: structured dtype in the order of
+    construct_list_of_attributes, f_dc / f_rest channel-major) loads into the arrays gaussian_model.py:342-420 builds;
+    save_ply writes the same bytes back; double-precision and shuffled property orders load too."""
+    import importlib
+    pkg = importlib.import_module("6dgs_amd")
+    rng = np.random.default_rng(0)
+    n, deg = 257, 3
+    xyz, nrm = rng.standard_normal((n, 3)).astype("f4"), np.zeros((n, 3), "f4")
+    f_dc_file = rng.standard_normal((n, 3)).astype("f4")               # f_dc_c   = channel c
+    f_rest_file = rng.standard_normal((n, 45)).astype("f4")             # f_rest_j = channel j // 15, coefficient j % 15
+    op, sc, rot = rng.standard_normal((n, 1)).astype("f4"), rng.standard_normal((n, 3)).astype("f4"), rng.standard_normal((n, 4)).astype("f4")
+    names = (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)] + ["opacity"]
+             + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)])
+    attrs = np.concatenate([xyz, nrm, f_dc_file, f_rest_file, op, sc, rot], axis=1)
+
+    def write(path, names, attrs, ftype="float", dt="<f4"):
+        el = np.empty(n, dtype=[(nm, dt) for nm in names])
+        for j, nm in enumerate(names):
+            el[nm] = attrs[:, j]
+        with open(path, "wb") as f:
+            f.write(b"ply\nformat binary_little_endian 1.0\ncomment written by the test\n")
+            f.write(f"element vertex {n}\n".encode() + "".join(f"property {ftype} {nm}\n" for nm in names).encode() + b"end_header\n")
+            f.write(el.tobytes())
+
+    p1 = str(tmp_path / "point_cloud.ply")
+    write(p1, names, attrs)
+    s = pkg.GaussianScene.load_ply(p1, deg, device="cpu")
+    assert len(s) == n and s.active_sh_degree == 3
+    assert np.array_equal(s._xyz.numpy(), xyz) and np.array_equal(s._opacity.numpy(), op)
+    assert np.array_equal(s._scaling.numpy(), sc) and np.array_equal(s._rotation.numpy(), rot)
+    assert s._features_dc.shape == (n, 1, 3) and np.array_equal(s._features_dc.numpy()[:, 0, :], f_dc_file)
+    assert s._features_rest.shape == (n, 15, 3)
+    assert np.array_equal(s._features_rest.numpy(), f_rest_file.reshape(n, 3, 15).transpose(0, 2, 1))
+    p2 = str(tmp_path / "out" / "point_cloud.ply")
+    s.save_ply(p2)
+    hdr_end = open(p2, "rb").read().index(b"end_header\n") + 11
+    assert open(p2, "rb").read()[hdr_end:] == attrs.astype("<f4").tobytes()
+    perm = rng.permutation(len(names))                                   # any property order, doubles
+    p3 = str(tmp_path / "shuffled.ply")
+    write(p3, [names[i] for i in perm], attrs[:, perm], "double", "<f8")
+    s3 = pkg.GaussianScene.load_ply(p3, deg, device="cpu")
+    for k in ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity"):
+        assert torch.equal(getattr(s, k), getattr(s3, k)), k
+    with pytest.raises(RuntimeError):
+        pkg.GaussianScene.load_ply(p1, 2, device="cpu")                    # wrong SH degree (gaussian_model.py:368)
