@@ -181,8 +181,11 @@ class BackboneWrapper(torch.nn.Module):
     # -- the two transform pipelines of backbone.py:52-77 ----------------------------------------------
     def transformations(self, x):
         x = _center_crop(_resize_short_side(x, 256, "bicubic"), 224)
-        mean = torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-        std = torch.tensor(IMAGENET_DEFAULT_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+        key = ("norm", x.dtype, str(x.device))          # device constants are built once (no H2D copy per call: the path
+        if key not in self._pe_cache:                   # stays capturable in a hipGraph)
+            self._pe_cache[key] = (torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1),
+                                   torch.tensor(IMAGENET_DEFAULT_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1))
+        mean, std = self._pe_cache[key]
         return (x - mean) / std
 
     def mask_transformations(self, m):

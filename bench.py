@@ -51,6 +51,9 @@ def parse():
                     help="matrix-core scheme of the logits kernel (default = the library's default mode)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="images whose [256,R] logits are resident at once (0 = as many of the batch as fit in 60 %% of the free HBM)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole per-batch path (image prep, ViT, CNN, scorer, pose solve) in one hipGraph and replay it "
+                         "per step: for the launch-bound small-scene regime (--mode reference); kernel timing needs the eager path")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
@@ -124,11 +127,32 @@ def main():
     gts = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams]).to(dev)
     prof = ops.KernelProfile()
 
+    graph, graph_sol = None, None
+
     def step(p):
-        sol = tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p)
+        if graph is not None:
+            graph.replay()
+            sol = graph_sol
+        else:
+            sol = tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p)
         c2w, st = dd.gather_poses(sol["c2w"], sol["status"], 0)
         host = (c2w if c2w is not None else sol["c2w"]).cpu()   # all poses on the host = end of the step
         return host, sol
+
+    if args.graph:
+        # The path is sync-free and works on caller-provided buffers, so the whole batch is one capturable stream of
+        # launches: ~300 kernel launches (ViT blocks, im2col GEMMs, scorer, top-k, solve) become one hipGraphLaunch.
+        step(None)                                    # eager once: lazy initialisation (weights packing, key cache, workspaces)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=None)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            graph_sol = tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=None)
+        graph = g
 
     for _ in range(args.warmup):
         step(None)
@@ -136,7 +160,7 @@ def main():
     dd.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        host_poses, sol = step(prof)
+        host_poses, sol = step(None if args.graph else prof)
     torch.cuda.synchronize()
     dd.barrier()
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, dev)
@@ -156,7 +180,7 @@ def main():
                             else "reference-mode quadricell emission from 1000 sampled ellipsoids")
                          + f" (R={R} rays), {args.image_size}x{args.image_size} uint8 queries, 256 tokens x 384, top-100, "
                          f"{args.batch} images/GPU/step; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
-            "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch, "images_per_logits_launch": inflight,
+            "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
             "parallelism": f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)",
         },
         "errors_vs_synthetic_gt": {"mean_translation": float(sol["errors"][:, 0].mean()), "mean_angular_deg": float(sol["errors"][:, 1].mean()),

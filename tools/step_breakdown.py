@@ -6,18 +6,23 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("6dgs_amd"); syn = importlib.import_module("6dgs_amd.synthetic")
 ops = importlib.import_module("6dgs_amd.ops"); tp = importlib.import_module("6dgs_amd.test")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
+MODE = sys.argv[2] if len(sys.argv) > 2 else "full"
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda", 0)
 scene = pkg.GaussianScene.from_dict(syn.make_scene(N, 0), device=dev)
 idm = pkg.IdentificationModule("dino")
 idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
 idm = idm.to(dev).eval()
-ori, dr, rgb = pkg.generate_all_possible_rays(scene, max_ellipsoids=-1, emitter="isocell", rays_per_ellipsoid=64)
-fin = torch.isfinite(dr).all(dim=1)
-ori, dr, rgb = ori[fin].contiguous(), dr[fin].contiguous(), rgb[fin].contiguous()
+if MODE == "full":
+    ori, dr, rgb = pkg.generate_all_possible_rays(scene, max_ellipsoids=-1, emitter="isocell", rays_per_ellipsoid=64)
+    fin = torch.isfinite(dr).all(dim=1)
+    ori, dr, rgb = ori[fin].contiguous(), dr[fin].contiguous(), rgb[fin].contiguous()
+else:
+    ori, dr, rgb = pkg.generate_all_possible_rays(scene)
 idm._ensure_keys(ori, dr, rgb)
 R = ori.shape[0]
-ws = torch.empty(ops.score_topk_workspace_bytes(R, 2, 100), dtype=torch.uint8, device=dev)
-cams = syn.make_cameras(4, 100, width=800, height=800)
+ws = torch.empty(ops.score_topk_workspace_bytes(R, min(BATCH, 2 if MODE == 'full' else BATCH), 100), dtype=torch.uint8, device=dev)
+cams = syn.make_cameras(BATCH, 100, width=800, height=800)
 images = [torch.from_numpy(c["image"]).to(dev) for c in cams]
 ev = lambda: torch.cuda.Event(enable_timing=True)
 for it in range(3):
