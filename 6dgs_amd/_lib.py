@@ -61,6 +61,8 @@ SIGNATURES = {
     "sixdgs_score_pass1": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, sz, vp, C.POINTER(Profile), i32]),
     "sixdgs_score_pass2": (i32, [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp, i32]),
     "sixdgs_score_topk_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile), i32]),
+    "sixdgs_linear_splitk_workspace_bytes": (sz, [i64, i32, i32]),
+    "sixdgs_linear_splitk": (i32, [vp, i64, i32, i64, vp, i64, vp, i32, i32, vp, i64, i32, vp, sz, vp, i32]),
     "sixdgs_linear_ex": (i32, [vp, i64, i32, i64, vp, i64, vp, i32, i32, vp, i64, vp, i32]),
     "sixdgs_profile_collect": (i32, [C.POINTER(Profile), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(i32)]),

@@ -40,6 +40,52 @@ __global__ void __launch_bounds__(256, 2) k_linear(GemmOperands g, const float* 
   }
 }
 
+// Split-K for GEMMs with few output tiles and a long K (the camera-up CNN as im2col: M = images x positions <= a few hundred,
+// K = 9600): grid.y slices K, every slice writes its partial tile to part[slice][M][N] and k_splitk_finish adds the slices in
+// ascending order (deterministic), then bias / ReLU.
+template <int MMA>
+__global__ void __launch_bounds__(256, 2) k_linear_splitk(GemmOperands g, int k_slice, float* __restrict__ part, unsigned n_tiles,
+                                                          unsigned total_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[TileSmem<MMA>::kBytes];
+  const unsigned w = xcd_remap(blockIdx.x, total_tiles);
+  const int64_t row0 = (int64_t)(w / n_tiles) * 128;
+  const int64_t col0 = (int64_t)(w % n_tiles) * kBN;
+  const int kb = (int)blockIdx.y * k_slice;
+  const int kl = min(k_slice, g.k - kb);
+  g.a0 += kb;
+  g.b += kb;
+  g.k = kl;
+  g.k0 = kl;
+  f32x16 acc[2][2];
+  gemm_tile<MMA>(g, row0, col0, smem, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* out = part + (int64_t)blockIdx.y * g.m * g.n;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = col0 + acc_col(wn, tn, lane);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + acc_row(wm, tm, r, lane);
+        if (row < g.m && col < g.n) out[row * g.n + col] = acc[tm][tn][r];
+      }
+  }
+}
+__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int slices, int64_t m, int n,
+                                                       const float* __restrict__ bias, int relu, float* __restrict__ y, int64_t ldy) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n) return;
+  const int64_t row = i / n;
+  const int col = (int)(i - row * n);
+  float v = 0.f;
+  for (int s = 0; s < slices; ++s) v += part[(int64_t)s * m * n + i];
+  if (bias) v += bias[col];
+  if (relu) v = fmaxf(v, 0.f);
+  y[row * ldy + col] = v;
+}
+
 int resolve_mma(int mode) {
   if (mode == SIXDGS_MMA_F32) return mode;
   return SIXDGS_MMA_BF16X6;  // DEFAULT, BF16X6 and F16X3 (the dense layers have no scaled-fp16 variant yet)
@@ -221,6 +267,34 @@ int sixdgs_linear_ex(const float* x, int64_t m, int k, int64_t ldx, const float*
   SDG_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0);
   GemmOperands g = {x, nullptr, w, ldx, 0, ldw, m, n, k, k};
   return launch_linear(g, b, relu != 0, y, ldy, sdg_stream(stream), mma_mode);
+}
+
+size_t sixdgs_linear_splitk_workspace_bytes(int64_t m, int n, int slices) {
+  return sdg_align((size_t)(m > 0 ? m : 1) * (size_t)(n > 0 ? n : 1) * (size_t)(slices > 0 ? slices : 1) * sizeof(float));
+}
+
+int sixdgs_linear_splitk(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n, int relu,
+                         float* y, int64_t ldy, int slices, void* ws, size_t ws_bytes, sixdgs_stream_t stream, int mma_mode) {
+  SDG_CHECK_ARG(m >= 0 && n > 0 && k > 0 && (k % 4) == 0 && (ldx % 4) == 0 && (ldw % 4) == 0 && ldx >= k && ldw >= k && ldy >= n);
+  SDG_CHECK_ARG(slices >= 1 && slices <= 1024);
+  if (m == 0) return 0;
+  SDG_CHECK_ARG(x && w && y && ws && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)ws % 16) == 0);
+  if (ws_bytes < sixdgs_linear_splitk_workspace_bytes(m, n, slices)) return SIXDGS_E_WORKSPACE;
+  int k_slice = (int)sdg_cdiv(sdg_cdiv(k, slices), 32) * 32;        // whole 32-wide k-slabs per slice
+  const int used = (int)sdg_cdiv(k, k_slice);
+  GemmOperands g = {x, nullptr, w, ldx, 0, ldw, m, n, k, k};
+  const int64_t m_tiles = sdg_cdiv(m, 128), n_tiles = sdg_cdiv(n, kBN);
+  const int64_t total = m_tiles * n_tiles;
+  if (total > 0x7fffffffLL) return SIXDGS_E_BADARG;
+  hipStream_t s = sdg_stream(stream);
+  const dim3 grid((unsigned)total, (unsigned)used), blk(256);
+  if (resolve_mma(mma_mode) == SIXDGS_MMA_BF16X6)
+    hipLaunchKernelGGL((k_linear_splitk<kMmaBf16x6>), grid, blk, 0, s, g, k_slice, (float*)ws, (unsigned)n_tiles, (unsigned)total);
+  else
+    hipLaunchKernelGGL((k_linear_splitk<kMmaF32>), grid, blk, 0, s, g, k_slice, (float*)ws, (unsigned)n_tiles, (unsigned)total);
+  hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)sdg_cdiv(m * n, 256)), dim3(256), 0, s, (const float*)ws, used, m, n, b, relu, y, ldy);
+  SDG_LAUNCH_OK();
+  return 0;
 }
 
 size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {

@@ -267,13 +267,26 @@ def ray_encode(ori, dr, rgb) -> torch.Tensor:
     return x
 
 
-def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None) -> torch.Tensor:
+def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, split_k: Optional[int] = None) -> torch.Tensor:
+    """y = x w^T + b (optionally ReLU).  split_k: None = automatic (K is cut into slices computed by separate workgroups when
+    the output has too few 128x128 tiles to fill the 256 CUs and K is long), 1 = never, n = that many slices."""
     x, w = _f32(x), _f32(w)
     _need_gpu(x, w)
     b = _f32(b) if b is not None else None
-    y = torch.empty(x.shape[0], w.shape[0], device=x.device)
-    check(_lib.load().sixdgs_linear_ex(_p(x), x.shape[0], x.shape[1], x.stride(0), _p(w), w.stride(0), _p(b), w.shape[0], int(relu),
-                                       _p(y), y.stride(0), _stream(), _mma_mode if mma_mode is None else mma_mode), "linear")
+    lib = _lib.load()
+    m, k, n = x.shape[0], x.shape[1], w.shape[0]
+    y = torch.empty(m, n, device=x.device)
+    mode = _mma_mode if mma_mode is None else mma_mode
+    if split_k is None:
+        tiles = -(-m // 128) * -(-n // 128)
+        split_k = 1 if (tiles >= 128 or k < 2048 or m == 0) else max(1, min(k // 256, -(-512 // tiles)))
+    if split_k > 1:
+        ws = torch.empty(lib.sixdgs_linear_splitk_workspace_bytes(m, n, split_k), dtype=torch.uint8, device=x.device)
+        check(lib.sixdgs_linear_splitk(_p(x), m, k, x.stride(0), _p(w), w.stride(0), _p(b), n, int(relu), _p(y), y.stride(0), int(split_k),
+                                       _p(ws), ws.numel(), _stream(), mode), "linear_splitk")
+    else:
+        check(lib.sixdgs_linear_ex(_p(x), m, k, x.stride(0), _p(w), w.stride(0), _p(b), n, int(relu), _p(y), y.stride(0), _stream(), mode),
+              "linear")
     return y
 
 

@@ -206,6 +206,12 @@ int sixdgs_linear(const float* x, int64_t m, int k, int64_t ldx, const float* w,
                   int relu, float* y, int64_t ldy, sixdgs_stream_t stream);
 int sixdgs_linear_ex(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
                      int relu, float* y, int64_t ldy, sixdgs_stream_t stream, int mma_mode);
+/* The same product with K cut into `slices` parts computed by separate workgroups and added in ascending order
+ * (deterministic): for few output tiles and a long K (the camera-up CNN as im2col GEMMs: M <= a few hundred, K = 9600). */
+size_t sixdgs_linear_splitk_workspace_bytes(int64_t m, int n, int slices);
+int sixdgs_linear_splitk(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
+                         int relu, float* y, int64_t ldy, int slices, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
+                         int mma_mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Scorer, image side (per batch of query images)

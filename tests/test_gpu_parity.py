@@ -384,6 +384,23 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
         assert (N(res[name][0]) == N(res["f32"][0])).all(), name
 
 
+@pytest.mark.parametrize("m,k,n", [(576, 9600, 384), (4, 6144, 384), (64, 9600, 384), (130, 2052, 37)])
+def test_linear_split_k_matches_single_pass(ops, m, k, n):
+    """Split-K (few output tiles, long K: the camera-up CNN as im2col GEMMs) adds the K slices in a fixed order: deterministic,
+    and equal to the single-pass product up to the re-association of the fp32 sum."""
+    rng = np.random.default_rng(m + n)
+    x = G(rng.standard_normal((m, k)).astype(np.float32))
+    w = G((rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = G(rng.standard_normal(n).astype(np.float32))
+    ref = (N(x).astype(np.float64) @ N(w).astype(np.float64).T + N(b)).clip(min=0)
+    y1 = ops.linear(x, w, b, relu=True, split_k=1)
+    for s in (None, 7, 32):
+        ys = ops.linear(x, w, b, relu=True, split_k=s)
+        assert torch.equal(ys, ops.linear(x, w, b, relu=True, split_k=s))            # deterministic
+        assert np.abs(N(ys) - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
+    assert np.abs(N(y1) - ref).max() < 3e-6 * max(1.0, np.abs(ref).max())
+
+
 def test_f16x3_tile_scaling_edge_cases(ops):
     """fp16x3 scorer on operands whose 128-row tiles differ by many orders of magnitude, with an all-zero tile, a ragged
     last tile and values far outside the fp16 range: the per-token max logit stays within the fp32 error bound of the
