@@ -75,17 +75,64 @@ def prepare_images_device(images):
     return out_i, out_m
 
 
+class _ImageSideGraph:
+    """hipGraph of the image side of a batch (uint8 -> fp32, resize / crop / normalise, ViT-S/14, token assembly, camera-up
+    CNN): ~250 small launches that are launch-bound at 4..16 images.  One graph per (module weights, batch shape); inputs are
+    copied into a static buffer, outputs are static tensors consumed in stream order before the next replay."""
+
+    def __init__(self):
+        self.key, self.graph, self.inp, self.out, self.failed = None, None, None, None, False
+
+    def run(self, id_module, images):
+        if self.failed or len(images) < 2 or not all(im.shape == images[0].shape and im.shape[-1] == 3 and im.dtype == torch.uint8 for im in images):
+            return None
+        key = (len(images), tuple(images[0].shape), str(images[0].device), next(id_module.parameters()).data_ptr(),
+               tuple(p._version for p in id_module.parameters()))
+        try:
+            if self.key != key:
+                self.inp = torch.stack(list(images))
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):               # warm-up on a side stream (lazy initialisation, allocator)
+                    self._body(id_module)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = self._body(id_module)
+                self.graph, self.key = g, key
+            else:
+                torch.stack(list(images), out=self.inp)
+            self.graph.replay()
+            return self.out
+        except Exception:                                   # capture unsupported (e.g. a backbone with host syncs): stay eager
+            self.failed, self.key, self.graph = True, None, None
+            return None
+
+    def _body(self, id_module):
+        imgs_f, masks = prepare_images_device(list(self.inp))
+        tokens, fmaps = id_module.image_tokens(imgs_f, masks)
+        return tokens, id_module.camera_up(fmaps)
+
+
 @torch.no_grad()
 def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
-                   images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False):
+                   images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False, image_graph: bool = True):
     """One batch of the hot path: query images (uint8 [H,W,3|4] tensors on the GPU) -> poses.
     image prep -> backbone tokens + camera-up (PyTorch-ROCm) -> q_proj / scorer / top-k / pose solve (HIP).
     `tokens` / `up` inject the image-side boundary inputs instead.  Everything is enqueued on the current
     stream; nothing syncs until the caller reads the returned device tensors."""
     if tokens is None:
-        imgs_f, masks = prepare_images_device(images)
-        tokens, fmaps = id_module.image_tokens(imgs_f, masks)
-        up = id_module.camera_up(fmaps)
+        res = None
+        if image_graph and not torch.cuda.is_current_stream_capturing():
+            cache = id_module.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
+            res = cache.run(id_module, images)
+        if res is not None and torch.is_tensor(res[0]):
+            tokens, up = res
+        else:
+            imgs_f, masks = prepare_images_device(images)
+            tokens, fmaps = id_module.image_tokens(imgs_f, masks)
+            up = id_module.camera_up(fmaps)
     idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
                                                   workspace=workspace, images_in_flight=images_in_flight, profile=profile)
     sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt_c2w)
