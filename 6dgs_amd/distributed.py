@@ -159,7 +159,7 @@ def merge_topk(idx_local: torch.Tensor, val: torch.Tensor, ray_offset: int, k: i
     """Per-rank top-k candidates (indices local to the rank's ray slice, -1 / NaN padded) -> the global top-k on every
     rank, ordered like the single-GPU kernel: value descending, ties by the lower global ray index."""
     gidx = torch.where(idx_local >= 0, idx_local + int(ray_offset), idx_local)
-    if is_dist():
+    if is_dist() and group is not False:           # group=False: merge the given candidates locally (streamed scoring)
         world = dist.get_world_size(group)
         dev = idx_local.device
         gi, gv = _collective_device(gidx.contiguous()), _collective_device(val.contiguous())

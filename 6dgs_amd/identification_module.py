@@ -195,6 +195,57 @@ class IdentificationModule(torch.nn.Module):
         return idx, val, scores
 
     @torch.no_grad()
+    def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608):
+        """The scorer without a resident key cache, for ray sets whose keys (1536 B/ray) plus logits (1 KB/ray/image) exceed
+        the GPU: the rays go through in chunks and every chunk's keys are computed, used and dropped -- twice, because the
+        softmax runs over ALL rays: sweep 1 collects each chunk's row statistics and merges them (M = max m_c,
+        S = sum s_c e^(m_c - M)), sweep 2 recomputes the chunk, finishes it with the global statistics and merges its top-k
+        candidates (value descending, global index ascending).  Same result as score_tokens up to the rounding of the sum of
+        exponentials; costs two ray-MLP and two logits passes.  Returns (idx [B,k], val [B,k]); no [B,R] score vector."""
+        dev = rays_ori.device
+        w = self.packed_weights(dev)
+        if torch.is_tensor(token_list):
+            tokens, n_tok = token_list.contiguous(), self._full_ntok(token_list.shape[0], dev)
+        else:
+            tokens, n_tok = ops.pad_tokens(token_list, dev)
+        q = ops.q_proj(tokens, n_tok, w)
+        b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
+        chunk = max(128, (min(chunk_rays, max(r, 1)) + 127) // 128 * 128)       # whole fp16 scale tiles
+        ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k), dtype=torch.uint8, device=dev)
+        f16 = ops.effective_mma_mode() == ops.MMA_F16X3
+
+        def chunk_pass1(r0):
+            r1 = min(r0 + chunk, r)
+            o, d, c = rays_ori[r0:r1].contiguous(), rays_dir[r0:r1].contiguous(), rays_rgb[r0:r1].contiguous()
+            if ops.effective_mma_mode() == ops.MMA_F32:
+                _, key = ops.ray_keys(o, d, c, w)
+                return ops.score_pass1(q, n_tok, key, ws, k), r1 - r0, False
+            _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
+            planes, scale = planes if f16 else (planes, None)
+            return ops.score_pass1(q, n_tok, None, ws, k, key_planes=planes, key_scale=scale), r1 - r0, True
+
+        m_g = torch.full((b, ops.MAX_TOKENS), -float("inf"), device=dev)
+        s_g = torch.zeros(b, ops.MAX_TOKENS, device=dev)
+        for r0 in range(0, r, chunk):                        # sweep 1: statistics
+            st, _, _ = chunk_pass1(r0)
+            m_c, s_c = st[..., 0], st[..., 1]
+            m_n = torch.maximum(m_g, m_c)
+            safe = torch.where(torch.isinf(m_n), torch.zeros_like(m_n), m_n)
+            s_g = s_g * torch.exp(torch.where(torch.isinf(m_g), torch.full_like(m_g, -float("inf")), m_g - safe)) + \
+                s_c * torch.exp(torch.where(torch.isinf(m_c), torch.full_like(m_c, -float("inf")), m_c - safe))
+            m_g = m_n
+        glob = torch.stack([m_g, s_g], dim=-1).contiguous()
+        best_i = torch.full((b, k), -1, dtype=torch.int64, device=dev)
+        best_v = torch.full((b, k), float("nan"), device=dev)
+        from . import distributed as dd
+        for r0 in range(0, r, chunk):                        # sweep 2: scores of the chunk, candidate merge
+            _, rl, planes_used = chunk_pass1(r0)
+            idx, val, _ = ops.score_pass2(glob, n_tok, rl, ws, k, used_planes=planes_used, want_scores=False)
+            gi = torch.where(idx >= 0, idx + r0, idx)
+            best_i, best_v = dd.merge_topk(torch.cat([best_i, gi], dim=1), torch.cat([best_v, val], dim=1), 0, k, group=False)
+        return best_i, best_v
+
+    @torch.no_grad()
     def test_images(self, imgs, masks, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, want_scores: bool = True,
                     workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None):
         """Batched test_image: returns dict(idx[B,k], values[B,k], scores[B,R]|None, camera_up_dir[B,3], n_tokens[B])."""

@@ -53,3 +53,32 @@ def test_single_process_split_passes_equal_the_fused_scorer():
     small = torch.empty(ops.score_topk_workspace_bytes(5000, 1, 100), dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError):                      # both images must stay resident between the passes
         ops.score_pass1(q, n_tok, None, small, 100, key_planes=pl, key_scale=sc)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_streamed_scorer_without_key_cache_matches_the_resident_one(mode):
+    """score_tokens_streamed (keys recomputed per ray chunk, two sweeps, nothing of size R x 384 resident) returns the
+    resident scorer's top-100."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module("6dgs_amd")
+    ops = importlib.import_module("6dgs_amd.ops")
+    syn = importlib.import_module("6dgs_amd.synthetic")
+    ops.set_mma_mode({"f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[mode])
+    try:
+        rays = syn.make_rays(9001, 2)
+        ori, dr, rgb = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+        idm = pkg.IdentificationModule("dino")
+        idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+        idm = idm.cuda().eval()
+        toks = [torch.from_numpy(syn.make_tokens(t, 40 + i, 40.0)).cuda() for i, t in enumerate((256, 77, 1))]
+        idx0, val0, _ = idm.score_tokens(toks, ori, dr, rgb, 100, want_scores=False)
+        for chunk in (2048, 4096 + 128, 1 << 20):
+            idx, val = idm.score_tokens_streamed(toks, ori, dr, rgb, 100, chunk_rays=chunk)
+            assert torch.equal(idx, idx0), chunk
+            assert float(((val - val0).abs() / val0.abs().clamp(min=1e-30)).max()) < 3e-6
+    finally:
+        ops.set_mma_mode(ops.MMA_DEFAULT)
