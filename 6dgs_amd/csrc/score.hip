@@ -469,12 +469,6 @@ __device__ __forceinline__ float load_uniform(const float* p) {
   return *reinterpret_cast<const __attribute__((address_space(4))) float*>((uintptr_t)p);
 }
 
-__device__ __forceinline__ f16x8 lds_read_frag_h(unsigned addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-
 __device__ __forceinline__ f16x8 lds_read_frag_h_off(unsigned addr, const int imm) {
   f16x8 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
