@@ -384,6 +384,32 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
         assert (N(res[name][0]) == N(res["f32"][0])).all(), name
 
 
+@pytest.mark.parametrize("r", [1, 37, 129, 300])
+def test_scorer_on_tiny_ray_sets(ops, oracle, r):
+    """Fewer rays than a tile / than k: scores against the oracle, top-k padded with (-1, NaN) beyond the r-th entry."""
+    rng = np.random.default_rng(r)
+    key = rng.standard_normal((r, 384)).astype(np.float32)
+    q = np.zeros((2, 256, 384), np.float32)
+    q[0, :200] = rng.standard_normal((200, 384)).astype(np.float32) * 0.3
+    q[1, :3] = rng.standard_normal((3, 384)).astype(np.float32) * 0.3
+    n_tok = torch.tensor([200, 3], dtype=torch.int32, device="cuda")
+    for mode in (ops.MMA_F16X3, ops.MMA_BF16X6, ops.MMA_F32):
+        ops.set_mma_mode(mode)
+        try:
+            kp, ks = (ops.split_planes_f16(G(key)) if mode == ops.MMA_F16X3 else
+                      ((ops.split_planes(G(key)), None) if mode == ops.MMA_BF16X6 else (None, None)))
+            idx, val, sc, _ = ops.score_topk(G(q), n_tok, G(key), 100, key_planes=kp, key_scale=ks)
+        finally:
+            ops.set_mma_mode(ops.MMA_DEFAULT)
+        for b, t in enumerate((200, 3)):
+            ref = oracle.attention_scores(q[b, :t], key)
+            assert np.abs(N(sc)[b] - ref).max() <= 1e-5 * np.abs(ref).max(), (mode, b)
+            assert abs(float(N(sc)[b].astype(np.float64).sum()) - t) < 1e-4 * t
+            n = min(r, 100)
+            order = np.lexsort((np.arange(r), -N(sc)[b]))[:n]
+            assert (N(idx)[b, :n] == order).all() and (N(idx)[b, n:] == -1).all() and np.isnan(N(val)[b, n:]).all()
+
+
 @pytest.mark.parametrize("m,k,n", [(576, 9600, 384), (4, 6144, 384), (64, 9600, 384), (130, 2052, 37)])
 def test_linear_split_k_matches_single_pass(ops, m, k, n):
     """Split-K (few output tiles, long K: the camera-up CNN as im2col GEMMs) adds the K slices in a fixed order: deterministic,
