@@ -730,7 +730,10 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
               acc[tm][tn][4 * rg + 1] = v.y;
               acc[tm][tn][4 * rg + 2] = v.z;
               acc[tm][tn][4 * rg + 3] = v.w;
-              if (!(ABL & 64)) *reinterpret_cast<float4*>(tb + tm * 4096 + tn * 1024 + rg * 256) = v;
+              if (!(ABL & 64)) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256));
+              }
               mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
             }
           const float mn = fmaxf(m_run[tm], mx);
