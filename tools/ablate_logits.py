@@ -25,7 +25,8 @@ n_tok = torch.full((2,), 256, dtype=torch.int32, device="cuda")
 ws = torch.empty(ops.score_topk_workspace_bytes(R, 2, 100), dtype=torch.uint8, device="cuda")
 names = {2048: "cycle stamps", 512: "nt key DMA", 1024: "nt q DMA", 1536: "nt key+q DMA", 256: "plain (temporal) stores", 64: "no logit stores", 128: "no exp/sum stats", 192: "no stores, no exp/sum", 3: "no Q DMA, no epilogue", 10: "no key DMA, no epilogue", 59: "MFMA only (no DMA/reads/epilogue/barriers)", 0: "full", 1: "Q DMA first tile only", 8: "key DMA first tile only", 9: "no DMA after first tile", 2: "no epilogue",
          4: "no MFMA", 13: "no MFMA, no DMA after first tile", 6: "no MFMA, no epilogue", 11: "no DMA, no epilogue", 27: "MFMA + barriers only (no DMA/reads/epilogue)", 18: "no frag reads, no epilogue"}
-for abl in (0, 2048):
+ABLS = tuple(int(a) for a in os.environ.get("ABLATE_LIST", "0,2,9,11,64,27,59,2048").split(","))
+for abl in ABLS:
     os.environ["SIXDGS_DEBUG_ABLATE"] = str(abl)
     for it in range(2):
         prof = ops.KernelProfile()
@@ -34,6 +35,8 @@ for abl in (0, 2048):
     print(f"ABL={abl:3d} {names[abl]:34s} {ms:8.2f} ms   {fl / ms / 1e9:7.1f} TFLOP/s-eq   per WG-tile {ms * 1e3 * 256 / (R / 128 * 4):6.2f} us")
 
 
+if 2048 not in ABLS:
+    sys.exit(0)
 import ctypes, numpy as np
 lib = ctypes.CDLL(abl_so)
 buf = (ctypes.c_ulonglong * 64)()
