@@ -250,10 +250,31 @@ def cpu_baseline(args, idm, ori, dr, rgb, R, sol):
     O.pose_from_topk(o_np, d_np, idx, val, up)
     t = time.perf_counter() - t0
     per_pose = t * (R / rs)
-    return {"value": round(1.0 / per_pose, 6), "unit": "poses/s", "cores": cores, "kind": "port",
-            "sample": f"per-pose path (q_proj + softmax scorer + top-100 + pose solve) on the first {rs} of {R} rays, "
-                      f"{t:.2f} s measured, scaled by R/sample; backbone/CNN excluded; scene set-up excluded",
-            "sample_seconds": round(t, 3)}
+    out = {"value": round(1.0 / per_pose, 6), "unit": "poses/s", "cores": cores, "kind": "port",
+           "sample": f"per-pose path (q_proj + softmax scorer + top-100 + pose solve) on the first {rs} of {R} rays, "
+                     f"{t:.2f} s measured, scaled by R/sample; backbone/CNN excluded; scene set-up excluded",
+           "sample_seconds": round(t, 3)}
+    # The port keeps the reference's scalar summation order (it is a parity oracle, not a tuned CPU code).  For scale, the
+    # same per-pose path written with PyTorch CPU ops (what the reference runs: blocked multi-threaded GEMM + softmax + topk)
+    # on the same sample, all host threads -- SURVEY 8(d) "the build's own PyTorch re-expression on device=cpu".
+    try:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+        k_t, tok_t = torch.from_numpy(key), torch.from_numpy(tok)
+        wq, bq = torch.from_numpy(sd["attention.q_proj.weight"]), torch.from_numpy(sd["attention.q_proj.bias"])
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            qt = tok_t @ wq.t() + bq
+            att = torch.softmax((qt @ k_t.t()) / (qt.shape[-1] ** 0.5), dim=-1)
+            sc = att.sum(dim=0)
+            torch.topk(sc, 100)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["torch_cpu"] = {"value": round(1.0 / (best * (R / rs)), 6), "unit": "poses/s", "threads": torch.get_num_threads(),
+                            "sample_seconds": round(best, 3), "note": "q_proj + softmax(QK^T) + column sum + top-100 with PyTorch CPU ops"}
+    except Exception as e:  # the port above is the contract; this figure is informative
+        out["torch_cpu"] = {"error": e.__class__.__name__}
+    return out
 
 
 if __name__ == "__main__":
