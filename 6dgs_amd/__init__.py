@@ -22,6 +22,7 @@ from .sampling import generate_all_possible_rays  # noqa: F401
 from .identification_module import IdentificationModule  # noqa: F401
 from .test import test_pose_estimation  # noqa: F401
 from .scene import CameraInfo  # noqa: F401
+from .distance_based_loss import DistanceBasedScoreLoss  # noqa: F401
 
 __all__ = ["GaussianModel", "GaussianScene", "CameraInfo", "generate_all_possible_rays", "IdentificationModule",
-           "test_pose_estimation"]
+           "test_pose_estimation", "DistanceBasedScoreLoss"]

@@ -72,6 +72,8 @@ SIGNATURES = {
     "sixdgs_score_topk": (i32, [vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "sixdgs_topk_workspace_bytes": (sz, [i64, i32, i32]),
     "sixdgs_topk": (i32, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),
+    "sixdgs_distance_target_workspace_bytes": (sz, [i64]),
+    "sixdgs_distance_target": (i32, [vp, vp, i64, vp, i32, vp, vp, vp, sz, vp]),
     "sixdgs_solve_pose": (i32, [vp, vp, i64, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
 }
 

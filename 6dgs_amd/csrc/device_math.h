@@ -427,6 +427,22 @@ SDG_HD bool solve_centre(const float* Rm, const float* q, float* centre) {
   return true;
 }
 // error_computation.py:3-8
+// distance_based_loss.py:5-71 (best_one_to_one_rays_selector, the part DistanceBasedScoreLoss.forward consumes): the raw target
+// score of one ray for the ground-truth c2w `pose` (row-major 4x4): 1 - tanh(distance of the camera centre to the ray, clamped
+// to the ray origin behind it), zeroed for origins behind the camera plane ((p/|p| + 1)/2 with p = (o - c) . z_cam; NaN at p = 0).
+SDG_HD float distance_target(const float* pose, const V3& o, const V3& d) {
+  const V3 c = v3(pose[3], pose[7], pose[11]);
+  const V3 v = v3(c.x - o.x, c.y - o.y, c.z - o.z);
+  const float t = dot(v, d);
+  const V3 cl = t < 0.f ? o : v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+  const float dist = norm(v3(cl.x - c.x, cl.y - c.y, cl.z - c.z));
+  const float target = 1.f - tanhf(dist);
+  const V3 z = v3(pose[2], pose[6], pose[10]);
+  const float p = dot(v3(o.x - c.x, o.y - c.y, o.z - c.z), z);
+  const float sgn = ((p / fabsf(p)) + 1.f) / 2.f;
+  return target * sgn;
+}
+
 SDG_HD void pose_errors(const float* gt, const float* pr, float* terr, float* aerr) {
   float d0 = gt[3] - pr[3], d1 = gt[7] - pr[7], d2 = gt[11] - pr[11];
   *terr = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);

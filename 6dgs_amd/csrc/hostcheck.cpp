@@ -115,4 +115,9 @@ int hc_solve_centre(const float* Rm, const float* q, float* c) { return solve_ce
 
 void hc_pose_errors(const float* gt, const float* pr, float* out2) { pose_errors(gt, pr, out2, out2 + 1); }
 
+void hc_distance_target(const float* pose, const float* ori, const float* dir, long long r, float* out) {
+  for (long long i = 0; i < r; ++i)
+    out[i] = distance_target(pose, v3(ori[3 * i], ori[3 * i + 1], ori[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+}
+
 }  // extern "C"

@@ -177,7 +177,63 @@ __global__ void __launch_bounds__(64) k_solve_pose(PoseArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DistanceBasedScoreLoss target scores (distance_based_loss.py:147-283): raw target per ray, sum, rescale so that the
+// targets sum to the token count.  HBM-bound: 24 B read + 4 B write per ray in the first sweep, 4 + 4 in the second.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_distance_target(const float* __restrict__ ori, const float* __restrict__ dir, int64_t r,
+                                                         const float* __restrict__ pose, float* __restrict__ target,
+                                                         double* __restrict__ partial) {
+  __shared__ double sm[4];
+  float P[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) P[i] = pose[i];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = distance_target(P, v3(ori[3 * i], ori[3 * i + 1], ori[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    target[i] = t;
+    acc += (double)t;
+  }
+  acc = sdg_wave_sum(acc);
+  if (sdg_lane() == 0) sm[sdg_wave()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void __launch_bounds__(256) k_distance_scale(float* __restrict__ target, int64_t r, const double* __restrict__ partial, int n_part,
+                                                        float n_tokens, float* __restrict__ d_sum) {
+  __shared__ float mult;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n_part; ++i) s += partial[i];              // fixed order: deterministic
+    const float sum = (float)s;
+    mult = (1.f / sum) * n_tokens;                                  // python scalar / tensor = reciprocal * scalar
+    if (blockIdx.x == 0 && d_sum) *d_sum = sum;
+  }
+  __syncthreads();
+  const float m = mult;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r; i += (int64_t)gridDim.x * blockDim.x) target[i] = target[i] * m;
+}
+
 }  // namespace
+
+extern "C" size_t sixdgs_distance_target_workspace_bytes(int64_t r) {
+  (void)r;
+  return 1024 * sizeof(double);
+}
+
+extern "C" int sixdgs_distance_target(const float* rays_ori, const float* rays_dir, int64_t r, const float* d_pose, int n_tokens,
+                                      float* target, float* d_sum, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(r >= 0 && n_tokens >= 0);
+  if (r == 0) return 0;
+  SDG_CHECK_ARG(rays_ori && rays_dir && d_pose && target && ws && ((uintptr_t)ws % 8) == 0);
+  if (ws_bytes < 1024 * sizeof(double)) return SIXDGS_E_WORKSPACE;
+  const int nb = (int)(sdg_cdiv(r, 256) < 1024 ? sdg_cdiv(r, 256) : 1024);
+  hipStream_t s = sdg_stream(stream);
+  hipLaunchKernelGGL(k_distance_target, dim3((unsigned)nb), dim3(256), 0, s, rays_ori, rays_dir, r, d_pose, target, (double*)ws);
+  hipLaunchKernelGGL(k_distance_scale, dim3((unsigned)nb), dim3(256), 0, s, target, r, (const double*)ws, nb, (float)n_tokens, d_sum);
+  SDG_LAUNCH_OK();
+  return 0;
+}
 
 extern "C" int sixdgs_solve_pose(const float* rays_ori, const float* rays_dir, int64_t r, const int64_t* idx, const float* val,
                                  int k, const float* up, const float* gt_c2w, int batch, float* c2w, int32_t* status,

@@ -435,6 +435,24 @@ def topk(scores: torch.Tensor, k: int = 100):
 
 
 # ---------------------------------------------------------------------------------------------
+# DistanceBasedScoreLoss target scores
+# ---------------------------------------------------------------------------------------------
+def distance_target(rays_ori, rays_dir, pose, n_tokens: int, want_sum: bool = False):
+    """Target scores [R] of distance_based_loss.py for the ground-truth c2w `pose` [4,4] (any device), summing to n_tokens."""
+    rays_ori, rays_dir = _f32(rays_ori), _f32(rays_dir)
+    _need_gpu(rays_ori, rays_dir)
+    lib = _lib.load()
+    r, dev = rays_ori.shape[0], rays_ori.device
+    pose = _f32(pose.to(dev)).reshape(16)
+    target = torch.empty(r, device=dev)
+    tot = torch.zeros(1, device=dev) if want_sum else None
+    ws = torch.empty(lib.sixdgs_distance_target_workspace_bytes(r), dtype=torch.uint8, device=dev)
+    check(lib.sixdgs_distance_target(_p(rays_ori), _p(rays_dir), r, _p(pose), int(n_tokens), _p(target), _p(tot), _p(ws), ws.numel(),
+                                     _stream()), "distance_target")
+    return (target, tot) if want_sum else target
+
+
+# ---------------------------------------------------------------------------------------------
 # pose
 # ---------------------------------------------------------------------------------------------
 def solve_pose(rays_ori, rays_dir, idx, val, up, gt_c2w=None):

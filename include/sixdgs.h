@@ -263,6 +263,14 @@ int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* id
  * Pose assembly (per image) -- replaces pose_estimation/test.py:157-198,216-218 with
  * line_intersection.py:5-34,75-154 and error_computation.py:3-8
  * ------------------------------------------------------------------------------------------- */
+/* SURVEY 8(f)#1, forward part: the target scores of DistanceBasedScoreLoss (distance_based_loss.py:5-71,179-222) for the
+ * ground-truth camera d_pose (device, row-major c2w 4x4): 1 - tanh(distance of the camera centre to each ray), zero for ray
+ * origins behind the camera plane, rescaled so that the targets sum to n_tokens.  d_sum (device scalar, may be NULL)
+ * receives the un-scaled sum.  The loss value mean((pred - target)^2) and its gradient stay with the caller (PyTorch). */
+size_t sixdgs_distance_target_workspace_bytes(int64_t r);
+int sixdgs_distance_target(const float* rays_ori, const float* rays_dir, int64_t r, const float* d_pose, int n_tokens,
+                           float* target /*[r]*/, float* d_sum, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+
 /* For each image b: duplicate-origin filter, unweighted LS centre (NaN when det < 1e-7),
  * exclude_negatives reweighting, watch direction, make_rotation_mat(-watch, up[b]), singular -> I,
  * c2w = [inv(R) | centre], NaN -> I4.

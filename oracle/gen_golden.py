@@ -517,13 +517,38 @@ def g8(m):
     save("g8_lossfn", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g9: DistanceBasedScoreLoss.forward (distance_based_loss.py:147-283) on the g7 rays
+# --------------------------------------------------------------------------------------
+def g9(m):
+    dl = importlib.import_module("pose_estimation.distance_based_loss")
+    g7d = np.load(os.path.join(OUT, "g7_e2e.npz"))
+    ori, dr = T(g7d["n3000_p50_ori"]), T(g7d["n3000_p50_dir"])
+    rng = np.random.default_rng(21)
+    out = {"n": np.int64(4)}
+    loss = dl.DistanceBasedScoreLoss()
+    inside = np.eye(4, dtype=np.float32)                     # a camera INSIDE the scene: half of the origins lie behind its plane
+    inside[:3, :3] = syn.random_rotation(np.random.default_rng(5))
+    inside[:3, 3] = [0.1, -0.2, 0.05]
+    for i in range(4):
+        pose = T(g7d[f"e2e{i}_gt_c2w"]) if i < 3 else T(inside)
+        K = T(np.array([[110.0, 0, 48], [0, 110.0, 48], [0, 0, 1]], np.float32))
+        pred = T((rng.random(ori.shape[0]) * 0.02).astype(np.float32))
+        ntok = [256, 137, 1, 200][i]
+        avg, comb = loss(pred, pose, K, ori, dr, ntok, (16, 16), model_up=None, obs_img_shape=(96, 96))
+        out[f"c{i}_pose"], out[f"c{i}_pred"], out[f"c{i}_ntok"] = N(pose), N(pred), np.int64(ntok)
+        out[f"c{i}_combined"], out[f"c{i}_loss"] = N(comb), np.float64(avg.item())
+        print(f"  g9 case {i}: loss {avg.item():.6e}  nonzero targets {int((comb > 0).sum())}/{comb.shape[0]}")
+    save("g9_distance_loss", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:

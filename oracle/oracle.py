@@ -236,3 +236,12 @@ def pose_errors(gt_c2w, pred_c2w):
     a = C.c_float(0)
     lib().o_pose_errors(_p(gt), _p(pr), C.byref(t), C.byref(a))
     return t.value, a.value
+
+
+def distance_target(rays_ori, rays_dir, pose, n_tokens):
+    """distance_based_loss.py target scores (sum = n_tokens) for the c2w `pose` [4,4]; returns (combined [R], raw sum)."""
+    o, d, pz = _f(rays_ori), _f(rays_dir), _f(np.asarray(pose, np.float32).reshape(16))
+    out = np.empty(o.shape[0], np.float32)
+    s = C.c_float(0)
+    lib().o_distance_target(_p(o), _p(d), C.c_int64(o.shape[0]), _p(pz), int(n_tokens), _p(out), C.byref(s))
+    return out, s.value

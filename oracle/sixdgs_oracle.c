@@ -967,3 +967,32 @@ void o_pose_errors(const float* gt_c2w, const float* pred_c2w, float* terr, floa
   ca = ca < -1.f ? -1.f : (ca > 1.f ? 1.f : ca);
   *aerr_deg = acosf(ca) * (float)(180.0 / PI_D);
 }
+
+/* SURVEY 8(f)#1 forward: pose_estimation/distance_based_loss.py:5-71 (target_score of best_one_to_one_rays_selector) and
+ * :204-222 (rescale to sum = total_number_of_features; python scalar / tensor = reciprocal * scalar).  The sum is taken in
+ * double (torch's fp32 pairwise sum agrees with it to ~1e-7). */
+void o_distance_target(const float* ori, const float* dir, int64_t r, const float* pose, int n_tokens, float* combined, float* sum_out) {
+  const float cx = pose[3], cy = pose[7], cz = pose[11];
+  const float zx = pose[2], zy = pose[6], zz = pose[10];
+  double s = 0.0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+  for (int64_t i = 0; i < r; ++i) {
+    const float ox = ori[3 * i], oy = ori[3 * i + 1], oz = ori[3 * i + 2];
+    const float dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    const float vx = cx - ox, vy = cy - oy, vz = cz - oz;
+    const float t = (vx * dx + vy * dy) + vz * dz;
+    float px = ox, py = oy, pz = oz;
+    if (!(t < 0.f)) { px = ox + t * dx; py = oy + t * dy; pz = oz + t * dz; }
+    const float ex = px - cx, ey = py - cy, ez = pz - cz;
+    const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
+    float target = 1.f - tanhf(dist);
+    const float p = ((ox - cx) * zx + (oy - cy) * zy) + (oz - cz) * zz;
+    target = target * (((p / fabsf(p)) + 1.f) / 2.f);
+    combined[i] = target;
+    s += (double)target;
+  }
+  const float sum = (float)s;
+  const float mult = (1.f / sum) * (float)n_tokens;
+  for (int64_t i = 0; i < r; ++i) combined[i] = combined[i] * mult;
+  if (sum_out) *sum_out = sum;
+}

@@ -154,6 +154,43 @@ def test_a24_loss_fn_branch(pkg, e2e, golden):
     assert abs(ls - float(g8["mean_loss"])) <= 1e-4 * abs(float(g8["mean_loss"])) and rc == float(g8["mean_recall"])
 
 
+def test_distance_based_score_loss_on_the_gpu(pkg, golden):
+    """6dgs_amd.DistanceBasedScoreLoss (targets from sixdgs_distance_target) against the reference's forward (g9): targets,
+    zero pattern, loss value, gradient with respect to the prediction; and as loss_fn of test_pose_estimation."""
+    g, g7 = golden("g9_distance_loss"), golden("g7_e2e")
+    ori, dr = G(g7["n3000_p50_ori"]), G(g7["n3000_p50_dir"])
+    loss = pkg.DistanceBasedScoreLoss()
+    for i in range(int(g["n"])):
+        pred = G(g[f"c{i}_pred"]).requires_grad_(True)
+        avg, comb = loss(pred, G(g[f"c{i}_pose"]), torch.eye(3).cuda(), ori, dr, int(g[f"c{i}_ntok"]), (16, 16), obs_img_shape=(96, 96))
+        ref = g[f"c{i}_combined"]
+        assert np.abs(N(comb) - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert ((N(comb) == 0) == (ref == 0)).all()
+        assert abs(float(avg) - float(g[f"c{i}_loss"])) <= 1e-5 * float(g[f"c{i}_loss"])
+        avg.backward()
+        assert np.abs(N(pred.grad) - 2 * (g[f"c{i}_pred"] - ref) / ref.shape[0]).max() < 1e-9
+    from oracle import oracle as O
+    comb, _ = O.distance_target(g7["n3000_p50_ori"], g7["n3000_p50_dir"], g["c3_pose"], 200)
+    import importlib
+    ops = importlib.import_module("6dgs_amd.ops")
+    t, s = ops.distance_target(ori, dr, G(g["c3_pose"]), 200, want_sum=True)
+    assert np.abs(N(t) - comb).max() <= 2e-6 * np.abs(comb).max() and abs(float(N(t).astype(np.float64).sum()) - 200) < 0.2
+
+
+def test_a24_with_the_native_distance_loss(pkg, e2e):
+    """test_pose_estimation(loss_fn=DistanceBasedScoreLoss()): the evaluation mode of the reference driver; the pose then comes
+    from the top-100 TARGET scores, i.e. rays through the ground-truth camera -> small translation error."""
+    g, idm, cams = e2e
+    n = int(g["e2e_n"])
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    toks = [G(g[f"e2e{i}_tokens"]) for i in range(n)]
+    ups = torch.stack([G(g[f"e2e{i}_up"]) for i in range(n)])
+    res, te, ae, ls, rc = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 1.0, 0.0]), loss_fn=pkg.DistanceBasedScoreLoss(),
+                                                   token_override=toks, up_override=ups, verbose=False, batch_size=4)
+    assert len(res) == n and ls > 0 and 0.0 <= rc <= 1.0
+    assert te < 0.5 * float(g["e2e_mean_terr"])           # ground-truth rays beat the random-weight prediction by far
+
+
 def test_scores_match_reference_through_module(pkg, e2e):
     g, idm, _ = e2e
     ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])

@@ -128,3 +128,18 @@ def test_rotation_centre_errors(hc, oracle, golden):
     e = np.zeros(2, np.float32)
     hc.hc_pose_errors(P(gt), P(pr), P(e))
     assert abs(e[0] - float(g["plain_terr"])) < 1e-5 and abs(e[1] - float(g["plain_aerr"])) < 1e-3
+
+
+def test_distance_target_per_ray(hc, oracle, golden):
+    """device_math.h: distance_target (the raw per-ray target of DistanceBasedScoreLoss) against the reference's output
+    (g9, rescaled by the golden's own multiplier) and the oracle."""
+    g, g7 = golden("g9_distance_loss"), golden("g7_e2e")
+    ori, dr = f32(g7["n3000_p50_ori"]), f32(g7["n3000_p50_dir"])
+    for i in range(int(g["n"])):
+        pose = f32(g[f"c{i}_pose"]).reshape(16)
+        raw = np.zeros(ori.shape[0], np.float32)
+        hc.hc_distance_target(P(pose), P(ori), P(dr), C.c_longlong(ori.shape[0]), P(raw))
+        comb, s = oracle.distance_target(ori, dr, pose, int(g[f"c{i}_ntok"]))
+        mult = np.float32(1.0) / np.float32(s) * np.float32(int(g[f"c{i}_ntok"]))
+        assert np.abs(raw * mult - comb).max() <= 2e-7 * np.abs(comb).max()
+        assert ((raw == 0) == (g[f"c{i}_combined"] == 0)).all()

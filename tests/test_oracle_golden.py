@@ -220,3 +220,19 @@ def test_a18_line_intersection_exact_point(oracle):
     d = c[None] - o
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     assert np.abs(oracle.line_intersection(o, d.astype(np.float32)) - c).max() < 1e-4
+
+
+def test_distance_based_score_loss_targets(oracle, golden):
+    """o_distance_target against DistanceBasedScoreLoss.forward of the reference (g9), including a
+    camera inside the scene (half of the targets zeroed by the behind-the-camera factor) and the loss value."""
+    g, g7 = golden("g9_distance_loss"), golden("g7_e2e")
+    ori, dr = g7["n3000_p50_ori"], g7["n3000_p50_dir"]
+    for i in range(int(g["n"])):
+        ref = g[f"c{i}_combined"]
+        comb, s = oracle.distance_target(ori, dr, g[f"c{i}_pose"], int(g[f"c{i}_ntok"]))
+        assert np.abs(comb - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert ((comb == 0) == (ref == 0)).all()
+        assert abs(float(comb.astype(np.float64).sum()) - int(g[f"c{i}_ntok"])) < 1e-3 * int(g[f"c{i}_ntok"])
+        loss = float(np.mean(np.square(g[f"c{i}_pred"].astype(np.float64) - comb.astype(np.float64))))
+        assert abs(loss - float(g[f"c{i}_loss"])) <= 1e-5 * float(g[f"c{i}_loss"])
+    assert (g["c3_combined"] == 0).mean() > 0.3
