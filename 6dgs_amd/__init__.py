@@ -23,6 +23,7 @@ from .identification_module import IdentificationModule  # noqa: F401
 from .test import test_pose_estimation  # noqa: F401
 from .scene import CameraInfo  # noqa: F401
 from .distance_based_loss import DistanceBasedScoreLoss  # noqa: F401
+from .train import train_id_module  # noqa: F401
 
 __all__ = ["GaussianModel", "GaussianScene", "CameraInfo", "generate_all_possible_rays", "IdentificationModule",
-           "test_pose_estimation", "DistanceBasedScoreLoss"]
+           "test_pose_estimation", "DistanceBasedScoreLoss", "train_id_module"]

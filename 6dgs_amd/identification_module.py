@@ -3,7 +3,7 @@
 Same constructor, same parameter names (the reference's id_module.th["model_state_dict"] loads with
 load_state_dict), same test_image() return tuple.  The ray side (RayPreprocessor MLP + k_proj) and
 the attention scorer + top-k run in the HIP library; the DINOv2 backbone and the camera-up CNN stay
-on PyTorch-ROCm.
+on PyTorch-ROCm.  `forward` is the differentiable training path (PyTorch autograd, reference-sized ray sets).
 
 Differences that make the path fast while keeping results:
   * the ray features/keys depend only on (rays, weights): they are computed ONCE per scene and cached
@@ -278,6 +278,35 @@ class IdentificationModule(torch.nn.Module):
             up = self.camera_up(fmap[None])[0]
         return scores[0], AttentionMapProxy(t_pe.shape[0], rays_ori.shape[0]), t_flat, up
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("IdentificationModule.forward is the TRAINING path (randperm over rays, autograd through the "
-                                  "scorer; identification_module.py:94-115) -- out of scope of the inference build (SURVEY.md §8(f) #1)")
+    # ---- training path: differentiable, PyTorch-ROCm autograd ------------------------------
+    @staticmethod
+    def _pe(x: torch.Tensor, freqs: int) -> torch.Tensor:
+        """ray_preprocessor.py:3-9: x[..., c] * 2^f laid out channel-major / frequency-minor, [sin | cos]."""
+        bands = torch.pow(2.0, torch.arange(freqs, device=x.device, dtype=torch.float32))
+        ph = (x.unsqueeze(-1) * bands).flatten(start_dim=-2)
+        return torch.cat((ph.sin(), ph.cos()), dim=-1)
+
+    def ray_features_autograd(self, rays_ori, rays_dir, rays_rgb) -> torch.Tensor:
+        """RayPreprocessor.forward (ray_preprocessor.py:36-46) with PyTorch ops, for autograd."""
+        rp = self.ray_preprocessor
+        x = torch.cat((rays_ori, rays_dir, rays_rgb, self._pe(rays_ori, rp.pospe), self._pe(rays_dir, rp.viewpe),
+                       self._pe(rays_rgb, rp.rgbpe)), dim=-1)
+        return rp.mlp2(torch.cat((rp.mlp(x), x), dim=-1))
+
+    def forward(self, img: torch.Tensor, mask: torch.Tensor, rays_ori: torch.Tensor, rays_dir: torch.Tensor, rays_rgb: torch.Tensor,
+                rays_to_test: int = -1):
+        """The TRAINING forward of the reference (identification_module.py:94-115 -> run_attention :77-92): a random permutation of
+        the rays, ray MLP, attention over the rays, column sum, camera-up head -- all PyTorch ops on the module's parameters so
+        that autograd reaches them (at the reference's 1000-ellipsoid training size, R ~ 3e4, this is a few ms on PyTorch-ROCm;
+        the HIP library serves inference, where R is three orders of magnitude larger).  Returns (scores [R'], attention map
+        [T, R'], image features [T, 384], camera-up [3], used_ray_ids [R'])."""
+        used = torch.randperm(rays_ori.shape[0], device=img.device, dtype=torch.long)
+        if rays_to_test != -1:
+            used = used[:rays_to_test]
+        t_pe, t_flat, fmap = self.backbone_wrapper(img, mask)
+        feat = self.ray_features_autograd(rays_ori[used], rays_dir[used], rays_rgb[used])
+        q, k = self.attention.q_proj(t_pe), self.attention.k_proj(feat)
+        attention_map = torch.softmax((q @ k.transpose(-2, -1)) / (q.shape[-1] ** 0.5), dim=-1)
+        scores = attention_map.sum(dim=0)
+        up = torch.nn.functional.normalize(self.camera_direction_prediction_network(fmap), dim=-1)
+        return scores, attention_map, t_flat, up, used

@@ -542,13 +542,66 @@ def g9(m):
     save("g9_distance_loss", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g10: one accumulated TRAINING step of the reference (train.py:106-170): forward, DistanceBasedScoreLoss + 0.1 x camera-up
+# loss, backward -- gradient norms and 512 sampled entries per parameter tensor
+# --------------------------------------------------------------------------------------
+def g10(m):
+    dl = importlib.import_module("pose_estimation.distance_based_loss")
+    g7d = np.load(os.path.join(OUT, "g7_e2e.npz"))
+    sd_np = syn.make_scorer_state_dict(0, with_cnn=True)
+    idm = _load_scorer(m, sd_np)
+    idm.train()
+    idm.backbone_wrapper.eval()
+    ori, dr, rgb = T(g7d["n3000_p50_ori"][:6000]), T(g7d["n3000_p50_dir"][:6000]), T(g7d["n3000_p50_rgb"][:6000])
+    tok_pe, fmap = T(g7d["e2e0_tokens"]), T(g7d["e2e0_fmap"])
+    tok_flat = fmap.permute(1, 2, 0).reshape(-1, fmap.shape[0])
+    idm.backbone_wrapper.forward = lambda img, mask: (tok_pe, tok_flat, fmap)     # the boundary's image-side inputs, injected
+    perms = []
+    orig = torch.randperm
+
+    def rec(*a, **k):
+        p_ = orig(*a, **k)
+        perms.append(p_.clone())
+        return p_
+
+    torch.manual_seed(77)
+    torch.randperm = rec
+    try:
+        scores, att, _, up, used = idm(torch.zeros(8, 8, 3), torch.ones(8, 8, dtype=torch.bool), ori, dr, rgb)
+    finally:
+        torch.randperm = orig
+    pose = T(g7d["e2e0_gt_c2w"])
+    K = T(np.array([[110.0, 0, 48], [0, 110.0, 48], [0, 0, 1]], np.float32))
+    model_up = T(np.array([0.0, 1.0, 0.0], np.float32))
+    loss_score, _ = dl.DistanceBasedScoreLoss()(scores, pose, K, ori[used], dr[used], att.shape[-2], idm.backbone_wrapper.backbone_wh, model_up=model_up)
+    cam_up = -0.5 * torch.cosine_similarity(model_up, up, dim=-1) + 0.5
+    combined = loss_score + 0.1 * cam_up
+    (combined / 32).backward()
+    out = {"perm": N(perms[0]), "scores": N(scores), "loss_score": np.float64(loss_score.item()), "cam_up": np.float64(cam_up.item()),
+           "combined": np.float64(combined.item()), "up": N(up), "n_rays": np.int64(6000)}
+    names = []
+    for name, p_ in idm.named_parameters():
+        if p_.grad is None or name.startswith("backbone_wrapper"):
+            continue
+        g = p_.grad.detach().reshape(-1).double().numpy()
+        idx = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else len(name) * 1009 + g.size).integers(0, g.size, 512)
+        out["gn_" + name] = np.float64(np.linalg.norm(g))
+        out["gi_" + name] = idx.astype(np.int64)
+        out["gv_" + name] = g[idx].astype(np.float32)
+        names.append(name)
+    out["names"] = np.array(names)
+    print(f"  g10: combined {combined.item():.6e}  {len(names)} parameter gradients")
+    save("g10_train_step", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:

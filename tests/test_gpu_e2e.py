@@ -191,6 +191,79 @@ def test_a24_with_the_native_distance_loss(pkg, e2e):
     assert te < 0.5 * float(g["e2e_mean_terr"])           # ground-truth rays beat the random-weight prediction by far
 
 
+def test_training_step_gradients_match_the_reference(pkg, golden, syn):
+    """one accumulated training step (train.py:106-170) -- IdentificationModule.forward with the reference's
+    ray permutation and the image-side boundary inputs injected, DistanceBasedScoreLoss + 0.1 x camera-up loss, backward --
+    against the reference's autograd (g10): scores, both loss terms, and every parameter gradient (norm + 512 sampled entries)."""
+    import importlib
+    tr = importlib.import_module("6dgs_amd.train")
+    g, g7 = golden("g10_train_step"), golden("g7_e2e")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+    idm = idm.cuda().train()
+    idm.backbone_wrapper.eval()
+    n = int(g["n_rays"])
+    ori, dr, rgb = G(g7["n3000_p50_ori"][:n]), G(g7["n3000_p50_dir"][:n]), G(g7["n3000_p50_rgb"][:n])
+    tok_pe, fmap = G(g7["e2e0_tokens"]), G(g7["e2e0_fmap"])
+    idm.backbone_wrapper.forward = lambda img, mask: (tok_pe, fmap.permute(1, 2, 0).reshape(-1, fmap.shape[0]), fmap)
+    perm = G(g["perm"])
+    orig = torch.randperm
+    torch.randperm = lambda *a, **k: perm
+    try:
+        scores, att, _, up, used = idm(torch.zeros(8, 8, 3, device="cuda"), torch.ones(8, 8, dtype=torch.bool, device="cuda"), ori, dr, rgb)
+    finally:
+        torch.randperm = orig
+    assert torch.equal(used, perm) and att.shape == (tok_pe.shape[0], n)
+    assert np.abs(N(scores) - g["scores"]).max() <= 2e-5 * np.abs(g["scores"]).max()
+    assert np.abs(N(up) - g["up"]).max() < 1e-5
+    model_up = torch.tensor([0.0, 1.0, 0.0], device="cuda")
+    loss_score, _ = pkg.DistanceBasedScoreLoss()(scores, G(g7["e2e0_gt_c2w"]), torch.eye(3).cuda(), ori[used], dr[used], att.shape[-2],
+                                                 idm.backbone_wrapper.backbone_wh, model_up=model_up)
+    cam_up = -0.5 * torch.cosine_similarity(model_up, up, dim=-1) + 0.5
+    combined = loss_score + 0.1 * cam_up
+    assert abs(float(loss_score) - float(g["loss_score"])) <= 1e-4 * float(g["loss_score"])
+    assert abs(float(cam_up) - float(g["cam_up"])) < 1e-5 and abs(float(combined) - float(g["combined"])) <= 1e-4 * float(g["combined"])
+    (combined / 32).backward()
+    params = dict(idm.named_parameters())
+    assert len(g["names"]) == 24
+    for name in g["names"]:
+        gr = params[str(name)].grad.detach().reshape(-1).double().cpu().numpy()
+        gn = float(g["gn_" + str(name)])
+        # (the biases of mlp2.2 and k_proj shift every logit of a token equally: their true gradient is 0, the reference's
+        #  1e-13 is rounding noise -- hence the absolute floors)
+        assert abs(np.linalg.norm(gr) - gn) <= 2e-4 * gn + 1e-10, name
+        gv = g["gv_" + str(name)]
+        assert np.abs(gr[g["gi_" + str(name)]] - gv).max() <= 1e-3 * np.abs(gv).max() + 1e-11, name
+
+
+def test_train_id_module_runs_and_learns(pkg, syn, tmp_path):
+    """The loop of train.py on a 2 000-Gaussian scene for a handful of iterations: rays from the HIP emitter, autograd forward,
+    HIP loss targets, Adafactor step, periodic evaluation through the HIP inference path, checkpoint in the reference layout."""
+    import functools
+    import types
+    torch.manual_seed(0)
+    scene = pkg.GaussianScene.from_dict(syn.make_scene(2000, 3), device="cuda")
+    cams = [pkg.CameraInfo(**c) for c in syn.make_cameras(3, 17, width=64, height=64)]
+    info = types.SimpleNamespace(train_cameras=cams, test_cameras=cams[:1])
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+    idm = idm.cuda()
+    before = {k: v.detach().clone() for k, v in idm.attention.state_dict().items()}
+    logged = []
+    ckpt = str(tmp_path / "id_module.th")
+    pkg.train_id_module(ckpt, "cuda", idm, functools.partial(pkg.generate_all_possible_rays, scene), info, "seq", "cat",
+                        n_iterations=4, gradient_accumulation_steps=2, display_every_n_iterations=2, val_every_n_iterations=4,
+                        log_fn=lambda tag, v, it: logged.append((tag, v, it)))
+    losses = [v for tag, v, _ in logged if tag == "train/loss"]
+    assert len(losses) == 4 and all(np.isfinite(losses))
+    assert any(tag == "val/avg_translation_error" for tag, _, _ in logged)
+    assert any(not torch.equal(before[k], v) for k, v in idm.attention.state_dict().items())       # the optimiser moved the weights
+    sd = torch.load(ckpt)
+    assert set(sd) == {"epoch", "model_state_dict", "optimizer_state_dict", "running_loss"} and sd["epoch"] == 4
+    idm2 = pkg.IdentificationModule("dino")
+    idm2.load_state_dict(sd["model_state_dict"])
+
+
 def test_scores_match_reference_through_module(pkg, e2e):
     g, idm, _ = e2e
     ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
