@@ -68,8 +68,16 @@ def test_state_dict_keys_match_reference(syn):
     assert all(k.startswith("backbone_wrapper.image_preprocessing_net") for k in res.missing_keys)
     assert idm.state_dict()["ray_preprocessor.mlp2.0.weight"].shape == (512, 653)
     assert idm.state_dict()["attention.q_proj.weight"].shape == (384, 398)
-    with pytest.raises(NotImplementedError):
-        idm(None)
+    # the training forward is plain PyTorch (autograd): it also runs on CPU tensors
+    rays = syn.make_rays(300, 1)
+    o, d, c = (torch.from_numpy(rays[k]) for k in ("ori", "dir", "rgb"))
+    torch.manual_seed(0)
+    scores, att, feat, up, used = idm(torch.rand(40, 40, 3), torch.ones(40, 40, dtype=torch.bool), o, d, c, rays_to_test=200)
+    assert scores.shape == (200,) and att.shape == (256, 200) and feat.shape == (256, 384) and up.shape == (3,) and used.shape == (200,)
+    assert abs(float(scores.sum()) - 256.0) < 1e-2 and abs(float(up.norm()) - 1.0) < 1e-5
+    (scores.square().sum() + up[0]).backward()
+    assert idm.attention.q_proj.weight.grad is not None and idm.ray_preprocessor.mlp[0].weight.grad.abs().sum() > 0
+    assert idm.camera_direction_prediction_network.mlp[2].weight.grad.abs().sum() > 0
 
 
 def test_image_prep_and_gt_pose_on_cpu(syn):
