@@ -18,7 +18,7 @@ of the per-rank top-k candidates -- a few KB per image, latency-bound, the only 
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist

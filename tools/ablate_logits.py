@@ -1,5 +1,5 @@
 """Timing-only ablations of the DMA-fed logits kernel (SIXDGS_DEBUG_ABLATE): which part of a tile costs what."""
-import importlib, os, subprocess, sys, time
+import importlib, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
