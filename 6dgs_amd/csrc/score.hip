@@ -852,12 +852,14 @@ __global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ 
   split_store8(lo, hi, dst + row * kRowBytes + (k8 >> 2) * 192 + (k8 & 3) * 16);
 }
 
-// merge the per-group partial statistics: stats[b][t] = (max, sumexp)
-__global__ void __launch_bounds__(kT) k_merge_stats(const float* __restrict__ partial, int n_groups, float* __restrict__ stats) {
-  const int bl = blockIdx.x, t = threadIdx.x;
+// merge the per-group partial statistics: stats[b][t] = (max, sumexp).  Four threads per token take every fourth group
+// (independent load chains), then one thread folds the four partials in a fixed order.
+__global__ void __launch_bounds__(4 * kT) k_merge_stats(const float* __restrict__ partial, int n_groups, float* __restrict__ stats) {
+  __shared__ float sm[4][kT][2];
+  const int bl = blockIdx.x, t = threadIdx.x % kT, j = threadIdx.x / kT;
   const float* p = partial + (int64_t)bl * n_groups * kT * 2;
   float m = -INFINITY, s = 0.f;
-  for (int g = 0; g < n_groups; ++g) {
+  for (int g = j; g < n_groups; g += 4) {
     const float mt = p[((int64_t)g * kT + t) * 2], st = p[((int64_t)g * kT + t) * 2 + 1];
     if (mt > -INFINITY) {
       const float mn = fmaxf(m, mt);
@@ -865,8 +867,24 @@ __global__ void __launch_bounds__(kT) k_merge_stats(const float* __restrict__ pa
       m = mn;
     }
   }
-  stats[((int64_t)bl * kT + t) * 2] = m;
-  stats[((int64_t)bl * kT + t) * 2 + 1] = s;
+  sm[j][t][0] = m;
+  sm[j][t][1] = s;
+  __syncthreads();
+  if (j == 0) {
+    m = -INFINITY;
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float mt = sm[q][t][0], st = sm[q][t][1];
+      if (mt > -INFINITY) {
+        const float mn = fmaxf(m, mt);
+        s = s * expf(m - mn) + st * expf(mt - mn);
+        m = mn;
+      }
+    }
+    stats[((int64_t)bl * kT + t) * 2] = m;
+    stats[((int64_t)bl * kT + t) * 2 + 1] = s;
+  }
 }
 
 // pass 2: score[r] = sum_{t < T} exp(l[t][r] - max_t) / sumexp_t   (softmax over rays, summed over tokens)
@@ -1342,7 +1360,7 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
           hipLaunchKernelGGL(k_logits<kMmaBf16x6>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
         }
       }
-      if (phase != 2) hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(kT), 0, s, partial, n_groups_used, stats);
+      if (phase != 2) hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(4 * kT), 0, s, partial, n_groups_used, stats);
       if (phase == 2) {        // the caller's global statistics replace the local ones
         hipError_t e = hipMemcpyAsync(stats, row_stats + (int64_t)b0 * kT * 2, (size_t)nb * kT * 2 * sizeof(float),
                                       hipMemcpyDeviceToDevice, s);
