@@ -1269,6 +1269,7 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
   int64_t bg = batch > 65535 ? 65535 : batch;
   while (bg >= 1 && topk_plan(r, (int)bg, topk).bytes + (size_t)bg * per_image > ws_bytes) --bg;
   if (bg < 1 || (phase != 0 && bg < batch)) return SIXDGS_E_WORKSPACE;   // the split phases keep every image resident
+  bg = sdg_cdiv(batch, sdg_cdiv(batch, bg));      // equal groups (6 images, room for 5: 3 + 3, not 5 + 1 -- the images of a group share the key stream)
   p.topk_bytes = topk_plan(r, (int)bg, topk).bytes;
   char* base = (char*)ws;
   char* topk_ws = base;
