@@ -116,6 +116,14 @@ class _ImageSideGraph:
 
 
 @torch.no_grad()
+def prime_image_graph(id_module, images) -> bool:
+    """Builds (or refreshes) the cached hipGraph of the image side for this batch shape ahead of time -- set-up work, like
+    the key cache; estimate_poses builds it lazily otherwise.  Returns whether a graph is in use."""
+    cache = id_module.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
+    return cache.run(id_module, images) is not None
+
+
+@torch.no_grad()
 def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
                    images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False, image_graph: bool = True):
     """One batch of the hot path: query images (uint8 [H,W,3|4] tensors on the GPU) -> poses.

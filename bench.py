@@ -124,6 +124,8 @@ def main():
     cams = syn.make_cameras(args.batch, 100 + rank, width=args.image_size, height=args.image_size)
     images = [torch.from_numpy(c["image"]).to(dev) for c in cams]
     gts = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams]).to(dev)
+    tp.prime_image_graph(idm, images)        # set-up, like the key cache: the hipGraph of the image side for this batch shape
+    torch.cuda.synchronize()
     prof = ops.KernelProfile()
 
     graph, graph_sol = None, None
