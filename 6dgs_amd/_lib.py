@@ -102,7 +102,7 @@ def load():
             raise RuntimeError(f"6dgs_amd: {LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sixdgs_abi_version() != 1:
+    if lib.sixdgs_abi_version() != 2:
         raise RuntimeError("6dgs_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 1
+#define SIXDGS_ABI_VERSION 2   /* 2: plane-format scorer entry points (key_planes + d_key_scale), pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
