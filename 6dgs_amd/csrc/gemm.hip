@@ -315,7 +315,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
-  const bool f16 = key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT);
+  const bool f16 = key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32 || mma_mode == SIXDGS_MMA_DEFAULT);
   SDG_CHECK_ARG(!f16 || key_inv_scale);
   const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float)));
   if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;

@@ -499,11 +499,16 @@ __device__ unsigned long long g_dbg_cycles[8][8];   // [wave][phase] summed over
 //   are issued in step 3, after the slab barrier.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBNX = 256;                // rays per tile
+// 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
+// references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
+// for that token in this tile).  0.766 x the bytes of fp32 logits, written once and read once per image.
+constexpr int kTileBytes24 = 98304 + 2048;
 constexpr int kQStageX = 256 * 64;       // one plane of one stage
 constexpr int kKBaseX = 4 * kQStageX;    // 64 KiB
 constexpr int kLdsX = kKBaseX + 6 * kQStageX;   // 160 KiB
 
-template <int ABL>
+// L24: the logits leave the kernel as 24-bit fixed point instead of fp32 (see kTileBytes24 below)
+template <int ABL, bool L24>
 __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
@@ -578,6 +583,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     };
     // logits of image bl, blocked by 128-ray tiles: [tile128][token group g = t / 32][ray quad][t % 32][r % 4]
     float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + lane * 4);
+    char* lg24 = reinterpret_cast<char*>(A.logits) + (int64_t)bl * kT * A.ldl * 4;   // same per-image region, 24-bit layout
     const char* kcur = A.kp + (int64_t)t_begin * kBNX * kRowF;
     int lim_cur = tile_lim(t_begin);
 
@@ -730,12 +736,31 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
               acc[tm][tn][4 * rg + 1] = v.y;
               acc[tm][tn][4 * rg + 2] = v.z;
               acc[tm][tn][4 * rg + 3] = v.w;
-              if (!(ABL & 64)) {
+              if (!L24 && !(ABL & 64)) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256));
               }
               mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));   // clamped duplicate rays cannot raise the max
             }
+          if (L24 && !(ABL & 64)) {
+            // 24-bit fixed point of (this lane's tile maximum - logit), resolution 2^-19, clamped at 32 (e^-32 of the
+            // largest term): an absolute error <= 2^-20 per logit, below the fp32 rounding of a logit of magnitude >= 16
+            typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+            char* t24 = lg24 + (int64_t)(2 * tile + wn) * kTileBytes24 + ((wm * 2 + tm) * 12288 + lane * 12);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                unsigned d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  d[j] = (unsigned)__float2uint_rn(fminf((mx - acc[tm][tn][4 * rg + j]) * 524288.f, 16777215.f));
+                const u32x3 w3 = {d[0] | (d[1] << 24), (d[1] >> 8) | (d[2] << 16), (d[2] >> 16) | (d[3] << 8)};
+                __builtin_nontemporal_store(w3, reinterpret_cast<u32x3*>(t24 + (tn * 8 + 2 * rg) * 384));
+                __builtin_amdgcn_sched_barrier(0);      // keeps the 64 encodes from being hoisted above the stores (spills)
+              }
+            reinterpret_cast<float*>(lg24 + (int64_t)(2 * tile + wn) * kTileBytes24 + 98304)[((wm * 2 + tm) * 2 + (lane >> 5)) * 32 + (lane & 31)] = mx;
+          }
           const float mn = fmaxf(m_run[tm], mx);
           float sum[4] = {0.f, 0.f, 0.f, 0.f};
           if (!ragged) {
@@ -905,6 +930,7 @@ __global__ void __launch_bounds__(256) k_score_reduce(const float* __restrict__ 
   scores[(int64_t)bl * score_stride + j] = s;
 }
 
+#define FASTEXP(x) __expf(x)   // v_exp_f32 path (2 ulp); with the reciprocal above the pass becomes HBM-bound instead of VALU-bound
 // pass 2 on the blocked logits of k_logits_f16x ([tile][token group 8][ray quad 32][token 32][ray 4]): a wave owns a pair of
 // ray quads (8 rays): lanes 0..31 / 32..63 hold the 32 tokens of a group for quad 2p / 2p+1, every load instruction reads
 // 1 KiB contiguous, the 8 token groups accumulate in registers and one butterfly over 32 lanes finishes the column sums.
@@ -919,7 +945,7 @@ __global__ void __launch_bounds__(256) k_score_reduce_blocked(const float* __res
   for (int g = 0; g < 8; ++g) {
     const int t = g * 32 + l31;
     mt[g] = stats[((int64_t)bl * kT + t) * 2];
-    st[g] = stats[((int64_t)bl * kT + t) * 2 + 1];
+    st[g] = 1.f / stats[((int64_t)bl * kT + t) * 2 + 1];     // reciprocal once per token: 1 multiply per logit instead of a division
   }
   const int64_t tile = blockIdx.x;
   const float* tb = logits + (int64_t)bl * kT * ldl + tile * (kT * kBN) + lane * 4;
@@ -932,10 +958,10 @@ __global__ void __launch_bounds__(256) k_score_reduce_blocked(const float* __res
     for (int g = 0; g < 8; ++g)
       if (g * 32 + l31 < T) {
         const float4 v = *reinterpret_cast<const float4*>(tb + g * 4096 + p * 256);
-        acc.x += expf(v.x - mt[g]) / st[g];
-        acc.y += expf(v.y - mt[g]) / st[g];
-        acc.z += expf(v.z - mt[g]) / st[g];
-        acc.w += expf(v.w - mt[g]) / st[g];
+        acc.x += FASTEXP(v.x - mt[g]) * st[g];
+        acc.y += FASTEXP(v.y - mt[g]) * st[g];
+        acc.z += FASTEXP(v.z - mt[g]) * st[g];
+        acc.w += FASTEXP(v.w - mt[g]) * st[g];
       }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
@@ -957,6 +983,67 @@ __global__ void __launch_bounds__(256) k_score_reduce_blocked(const float* __res
     }
   }
 }
+
+// the same on the 24-bit fixed-point logits (kTileBytes24)
+__global__ void __launch_bounds__(256) k_score_reduce_blocked24(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ stats,
+                                                               const int* __restrict__ n_tok, int b0, int64_t R,
+                                                               float* __restrict__ scores, int64_t score_stride) {
+  const int bl = blockIdx.y;
+  const int T = n_tok[b0 + bl];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+  float mt[8], st[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int t = g * 32 + l31;
+    mt[g] = stats[((int64_t)bl * kT + t) * 2];
+    st[g] = 1.f / stats[((int64_t)bl * kT + t) * 2 + 1];     // reciprocal once per token: 1 multiply per logit instead of a division
+  }
+  const int64_t tile = blockIdx.x;
+  const char* tb = reinterpret_cast<const char*>(logits) + (int64_t)bl * kT * ldl * 4 + tile * kTileBytes24;
+  float refv[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) refv[g] = reinterpret_cast<const float*>(tb + 98304)[(g * 2 + (lane >> 5)) * 32 + l31];
+  float* out = scores + (int64_t)bl * score_stride + tile * kBN;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = u * 4 + wave;                 // quad pair
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      if (g * 32 + l31 < T) {
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 w3 = *reinterpret_cast<const u32x3*>(tb + g * 12288 + p * 768 + lane * 12);
+        float4 v;
+        v.x = refv[g] - (float)(w3.x & 0xffffffu) * 1.9073486328125e-06f;
+        v.y = refv[g] - (float)((w3.x >> 24) | ((w3.y & 0xffffu) << 8)) * 1.9073486328125e-06f;
+        v.z = refv[g] - (float)((w3.y >> 16) | ((w3.z & 0xffu) << 16)) * 1.9073486328125e-06f;
+        v.w = refv[g] - (float)(w3.z >> 8) * 1.9073486328125e-06f;
+        acc.x += FASTEXP(v.x - mt[g]) * st[g];
+        acc.y += FASTEXP(v.y - mt[g]) * st[g];
+        acc.z += FASTEXP(v.z - mt[g]) * st[g];
+        acc.w += FASTEXP(v.w - mt[g]) * st[g];
+      }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64);
+      acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64);
+      acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (l31 == 0) {
+      const int64_t r0 = tile * kBN + p * 8 + (lane >> 5) * 4;
+      float* o4 = out + p * 8 + (lane >> 5) * 4;
+      if (r0 + 3 < R && ((uintptr_t)o4 & 15) == 0) *reinterpret_cast<float4*>(o4) = acc;
+      else {   // ragged end of the scene, or a caller buffer whose row stride R is not a multiple of 4
+        if (r0 < R) o4[0] = acc.x;
+        if (r0 + 1 < R) o4[1] = acc.y;
+        if (r0 + 2 < R) o4[2] = acc.z;
+        if (r0 + 3 < R) o4[3] = acc.w;
+      }
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // top-k: 4-pass MSB radix select on an order-preserving key, ordered gather, bitonic sort
@@ -1254,10 +1341,11 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
                float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && batch >= 0 && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
-  const bool f16_mode = mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT;
+  const bool f16_mode = mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32 || mma_mode == SIXDGS_MMA_DEFAULT;
   const bool use_f16 = (phase == 2 ? planes : key_planes != nullptr) && f16_mode;
   SDG_CHECK_ARG(phase == 2 || !use_f16 || d_key_scale != nullptr);
   const bool use_v2 = (phase == 2 ? planes : key_planes != nullptr) && mma_mode != SIXDGS_MMA_F32;
+  const bool logits24 = mma_mode != SIXDGS_MMA_F16X3_L32;         // 24-bit fixed-point logits between the passes (fp16x3 path)
   SDG_CHECK_ARG(d_n_tok && ws && (phase == 2 || (q && (key || use_v2 || r == 0))) && (phase == 1 || (idx && val)) &&
                 (phase == 0 || row_stats));
   SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
@@ -1292,9 +1380,10 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
         double tok = 0.0;  // algorithmic work of this launch: 2*T*d FLOP and d*4 (key) + T*4 (logit) bytes per ray and image
         for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
         // operand bytes per ray: 1536 B fp32 key or 2304 B of bf16 planes per image; the fp16x3 kernel streams its 1536 B of
-        // fp16 planes once per LAUNCH (the images of a launch share every key tile through L2)
+        // fp16 planes once per LAUNCH (the images of a launch share every key tile through L2) and writes 3 (+1/16 for the
+        // references) or 4 bytes per logit
         SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r,
-                              use_f16 ? (double)r * (kRowF + tok * 4.0)
+                              use_f16 ? (double)r * (kRowF + tok * (logits24 ? 3.0 + 8.0 / 128.0 : 4.0))
                                       : (double)r * (nb * (use_v2 ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
         if (use_f16) {
           // scaled fp16 planes of q (one power-of-two scale per 128-token half), then the fp16x3 kernel
@@ -1315,10 +1404,10 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
           V.tiles_per_group = tpg_x;
           V.n_tiles = n_tiles_x;
           V.n_groups = n_groups_used;
-          auto kern = k_logits_f16x<0>;
+          auto kern = logits24 ? k_logits_f16x<0, true> : k_logits_f16x<0, false>;
 #ifdef SIXDGS_ABLATION   // timing experiments only (tools/ablate_logits.py builds a private copy of the library with it)
           if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
-#define SDG_ABL_CASE(n) case n: kern = k_logits_f16x<n>; break;
+#define SDG_ABL_CASE(n) case n: kern = logits24 ? k_logits_f16x<n, true> : k_logits_f16x<n, false>; break;
             switch (atoi(ab)) {
               SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
               SDG_ABL_CASE(64) SDG_ABL_CASE(2048)
@@ -1374,7 +1463,10 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
         SDG_LAUNCH_OK();
         continue;
       }
-      if (use_f16)
+      if (use_f16 && logits24)
+        hipLaunchKernelGGL(k_score_reduce_blocked24, dim3((unsigned)p.n_tiles, (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats,
+                           d_n_tok, b0, r, sc, sc_stride);
+      else if (use_f16)
         hipLaunchKernelGGL(k_score_reduce_blocked, dim3((unsigned)p.n_tiles, (unsigned)nb), dim3(256), 0, s, logits, A.ldl, stats, d_n_tok,
                            b0, r, sc, sc_stride);
       else

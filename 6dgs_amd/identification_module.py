@@ -118,7 +118,7 @@ class IdentificationModule(torch.nn.Module):
             scale = None
             if planes_mode:
                 _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True)
-                if mode == ops.MMA_F16X3:
+                if mode in ops.F16_MODES:
                     planes, scale = planes
             else:
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
@@ -212,7 +212,7 @@ class IdentificationModule(torch.nn.Module):
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
         chunk = max(128, (min(chunk_rays, max(r, 1)) + 127) // 128 * 128)       # whole fp16 scale tiles
         ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k), dtype=torch.uint8, device=dev)
-        f16 = ops.effective_mma_mode() == ops.MMA_F16X3
+        f16 = ops.effective_mma_mode() in ops.F16_MODES
 
         def chunk_pass1(r0):
             r1 = min(r0 + chunk, r)

@@ -12,7 +12,8 @@ from . import _lib
 from ._lib import Profile, ScorerWeights, check
 
 D = 384
-MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3 = -1, 0, 1, 2
+MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3, MMA_F16X3_L32 = -1, 0, 1, 2, 3
+F16_MODES = (MMA_F16X3, MMA_F16X3_L32)     # scaled fp16 key planes; they differ in how the logits are stored between the passes
 MMA_LIBRARY_DEFAULT = MMA_F16X3
 _mma_mode = MMA_DEFAULT
 
@@ -20,7 +21,7 @@ _mma_mode = MMA_DEFAULT
 def set_mma_mode(mode: int):
     """Select how the fp32 contractions run on the matrix cores (see SIXDGS_MMA_* in include/sixdgs.h)."""
     global _mma_mode
-    assert mode in (MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3)
+    assert mode in (MMA_DEFAULT, MMA_F32, MMA_BF16X6, MMA_F16X3, MMA_F16X3_L32)
     _mma_mode = mode
 
 
@@ -321,7 +322,7 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     feat = torch.empty(r, D, device=dev) if want_feat else None
     key = torch.empty(r, D, device=dev) if want_key else None
     mode = effective_mma_mode()
-    f16 = want_planes and mode == MMA_F16X3
+    f16 = want_planes and mode in F16_MODES
     planes = torch.empty(r, 1536 if f16 else 2304, dtype=torch.uint8, device=dev) if want_planes else None
     inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
@@ -383,8 +384,8 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
     mode = effective_mma_mode()
     if key_planes is not None and mode != MMA_F32:
-        want = 1536 if mode == MMA_F16X3 else 2304
-        if key_planes.shape[1] != want or (mode == MMA_F16X3 and key_scale is None):
+        want = 1536 if mode in F16_MODES else 2304
+        if key_planes.shape[1] != want or (mode in F16_MODES and key_scale is None):
             raise RuntimeError("6dgs_amd: key planes are not in the format of the active MMA mode")
     check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
                                    _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,

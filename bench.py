@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--mode", choices=["full", "reference"], default="full",
                     help="full: every Gaussian, iso-cell emitter (headline); reference: 1000-ellipsoid quadricell subsample")
     ap.add_argument("--image-size", type=int, default=800)
-    ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f32"], default="default",
+    ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f16x3l32", "f32"], default="default",
                     help="matrix-core scheme of the logits kernel (default = the library's default mode)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="images whose [256,R] logits are resident at once (0 = as many of the batch as fit in 60 %% of the free HBM)")
@@ -66,7 +66,7 @@ def main():
     dd = importlib.import_module("6dgs_amd.distributed")
     ops = importlib.import_module("6dgs_amd.ops")
     tp = importlib.import_module("6dgs_amd.test")
-    ops.set_mma_mode({"default": ops.MMA_DEFAULT, "bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[args.mma])
+    ops.set_mma_mode({"default": ops.MMA_DEFAULT, "bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f16x3l32": ops.MMA_F16X3_L32, "f32": ops.MMA_F32}[args.mma])
 
     # test hooks (tests/ and CI only): run the N > 1 code path with several ranks on one device over gloo
     forced_dev = os.environ.get("SIXDGS_BENCH_FORCE_DEVICE")
@@ -191,7 +191,7 @@ def main():
     }
     if rank == 0:
         mode = ops.effective_mma_mode()
-        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3"}[mode]
+        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3", ops.MMA_F16X3_L32: "f16x3l32"}[mode]
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
@@ -201,14 +201,15 @@ def main():
             except Exception:
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0
-        terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3}[mode]
+        terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3, ops.MMA_F16X3_L32: 3}[mode]
         peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_BF16_MFMA_TFLOPS / terms
         out["roofline"] = {
             "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
                                        "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
                        ops.MMA_F16X3: "k_logits_f16x: q.K^T (256 tokens x 256 rays per tile) with fp32 operands scaled by a power of two and split "
                                       "into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA rings, "
-                                      "online row stats, logits stored once",
+                                      "online row stats, logits stored once as 24-bit fixed point",
+                       ops.MMA_F16X3_L32: "k_logits_f16x: as f16x3 with the logits stored as fp32",
                        ops.MMA_F32: "k_logits<f32>: q.K^T on v_mfma_f32_32x32x2_f32, online row stats, logits stored once"}[mode],
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),

@@ -57,6 +57,11 @@ typedef void* sixdgs_stream_t;
  *           MFMA work of BF16X6 and fp32-sized operands; the dense layers run BF16X6 in this mode.
  *   DEFAULT = F16X3 (scorer) + BF16X6 (dense layers). */
 #define SIXDGS_MMA_F16X3 2
+/*   F16X3_L32  as F16X3, but the logits travel between the two scorer passes as fp32 (1 KiB per ray and image).  F16X3
+ *           stores them as 24-bit fixed point of (lane maximum - logit), resolution 2^-19 (absolute error <= 2^-20 per logit,
+ *           the fp32 rounding of a logit of magnitude 16; measured effect on the scores <= 5e-7 relative): 768 B per ray and
+ *           image through HBM twice, the largest data stream of the path. */
+#define SIXDGS_MMA_F16X3_L32 3
 
 /* Optional kernel timing, owned by the caller (the library stays stateless): zero-initialise, pass to
  * the *_ex entry points; each launch of the dominant kernel is bracketed by a pair of HIP events on

@@ -222,10 +222,10 @@ def test_a10_sh_colour(ops, golden, deg):
 # ------------------------------------------------------------------------------------------------
 # scorer
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module", params=["bf16x6", "f16x3", "f32"])
+@pytest.fixture(scope="module", params=["bf16x6", "f16x3", "f16x3l32", "f32"])
 def scorer(request, ops, oracle, golden, syn):
     """Runs every scorer test under all three matrix-core modes."""
-    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[request.param])
+    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f16x3l32": ops.MMA_F16X3_L32, "f32": ops.MMA_F32}[request.param])
     request.addfinalizer(lambda: ops.set_mma_mode(ops.MMA_DEFAULT))
     g = golden("g5_scorer")
     sd = syn.make_scorer_state_dict(0)
@@ -235,7 +235,7 @@ def scorer(request, ops, oracle, golden, syn):
     ofeat, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
     # bf16x6 / f16x3 modes score through the DMA-fed kernels on pre-split planes; f32 mode on the fp32 keys
     kscale = None
-    if request.param == "f16x3":
+    if request.param in ("f16x3", "f16x3l32"):
         planes, kscale = planes
         # the planes written chunk by chunk behind k_proj are those of a single split pass over the finished keys
         p2, s2 = ops.split_planes_f16(key)
@@ -365,10 +365,11 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
     res = {}
     p16, s16 = ops.split_planes_f16(key)
     for name, mode, kp, ks in (("f32", ops.MMA_F32, None, None), ("b6", ops.MMA_BF16X6, None, None),
-                               ("b6dma", ops.MMA_BF16X6, ops.split_planes(key), None), ("f16x3", ops.MMA_F16X3, p16, s16)):
+                               ("b6dma", ops.MMA_BF16X6, ops.split_planes(key), None), ("f16x3", ops.MMA_F16X3, p16, s16),
+                               ("f16x3l32", ops.MMA_F16X3_L32, p16, s16)):
         ops.set_mma_mode(mode)
         res[name] = ops.score_topk(q, n_tok, key, 100, key_planes=kp, key_scale=ks)
-    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f32": ops.MMA_F32}[scorer["mode"]])
+    ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f16x3l32": ops.MMA_F16X3_L32, "f32": ops.MMA_F32}[scorer["mode"]])
     # the scaled fp16 planes reproduce the keys to 2^-22 relative to the largest key of each 128-ray tile
     kn = N(key).astype(np.float64)
     inv = N(s16).astype(np.float64)
@@ -379,7 +380,9 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
         blk = kn[t * 128:(t + 1) * 128]
         assert np.abs(rec[t * 128:(t + 1) * 128] * inv[t] - blk).max() <= 2.0 ** -22 * np.abs(blk).max()
         assert 2.0 ** 13 <= np.abs(blk).max() / inv[t] < 2.0 ** 14
-    for name in ("b6", "b6dma", "f16x3"):
+    # the 24-bit logits change no bit of the row statistics and move the scores by < 1e-6
+    assert float((res["f16x3"][2] - res["f16x3l32"][2]).abs().max() / res["f16x3l32"][2].abs().max()) < 1e-6
+    for name in ("b6", "b6dma", "f16x3", "f16x3l32"):
         assert rel_err(N(res[name][2]), N(res["f32"][2])) < 5e-6, name
         assert (N(res[name][0]) == N(res["f32"][0])).all(), name
 
