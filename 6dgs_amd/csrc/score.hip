@@ -919,14 +919,17 @@ __global__ void __launch_bounds__(256) k_score_reduce(const float* __restrict__ 
   __shared__ float st[kT][2];
   const int bl = blockIdx.y;
   const int T = n_tok[b0 + bl];
-  for (int i = threadIdx.x; i < kT * 2; i += blockDim.x) (&st[0][0])[i] = stats[(int64_t)bl * kT * 2 + i];
+  for (int i = threadIdx.x; i < kT * 2; i += blockDim.x) {   // (max, 1 / sumexp): one multiply per logit instead of a division
+    const float v = stats[(int64_t)bl * kT * 2 + i];
+    (&st[0][0])[i] = (i & 1) ? 1.f / v : v;
+  }
   __syncthreads();
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= R) return;
   const float* l = logits + (int64_t)bl * kT * ldl + j;
   float s = 0.f;
 #pragma unroll 8
-  for (int t = 0; t < T; ++t) s += expf(l[(int64_t)t * ldl] - st[t][0]) / st[t][1];
+  for (int t = 0; t < T; ++t) s += __expf(l[(int64_t)t * ldl] - st[t][0]) * st[t][1];
   scores[(int64_t)bl * score_stride + j] = s;
 }
 
