@@ -26,4 +26,5 @@ for it in range(3):
         idx, val, sc = ops.score_pass2(st, n_tok, R, ws, 100, used_planes=True, want_scores=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / 5
-    print(f"pass 2 (reduce + top-k), {B} images x {R} rays: {ms:.2f} ms  -> logits stream {B * R * 1024 / ms / 1e9:.2f} TB/s incl. top-k")
+    bpr = 784 if ops.effective_mma_mode() == ops.MMA_F16X3 else 1024      # bytes of logits per ray and image (24-bit + references / fp32)
+    print(f"pass 2 (reduce + top-k), {B} images x {R} rays: {ms:.2f} ms  -> logits stream {B * R * bpr / ms / 1e9:.2f} TB/s incl. top-k")
