@@ -69,6 +69,7 @@ SIGNATURES = {
     "sixdgs_linear": (i32, [vp, i64, i32, i64, vp, i64, vp, i32, i32, vp, i64, vp]),
     "sixdgs_q_proj": (i32, [vp, vp, i32, C.POINTER(ScorerWeights), vp, vp]),
     "sixdgs_score_topk_workspace_bytes": (sz, [i64, i32, i32]),
+    "sixdgs_score_topk_workspace_bytes_ex": (sz, [i64, i32, i32, i32, i32]),
     "sixdgs_score_topk": (i32, [vp, vp, i32, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp]),
     "sixdgs_topk_workspace_bytes": (sz, [i64, i32, i32]),
     "sixdgs_topk": (i32, [vp, i64, i32, i32, vp, vp, vp, sz, vp]),

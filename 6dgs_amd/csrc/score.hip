@@ -1273,13 +1273,14 @@ struct ScorePlan {
   size_t per_image_logits, per_image_partial, per_image_stats, per_image_scores, per_image_qplanes, topk_bytes;
   size_t per_image() const { return per_image_logits + per_image_partial + per_image_stats + per_image_scores + per_image_qplanes; }
 };
-ScorePlan score_plan(int64_t r, int batch, int topk) {
+ScorePlan score_plan(int64_t r, int batch, int topk, bool logits24 = false) {
   ScorePlan p;
   p.ldl = sdg_cdiv(r > 0 ? r : 1, 256) * 256;   // whole 256-ray tiles (k_logits_f16x)
   p.n_tiles = (int)sdg_cdiv(r > 0 ? r : 1, kBN);
   p.tiles_per_group = (int)sdg_cdiv(p.n_tiles, 2048);
   p.n_groups = (int)sdg_cdiv(p.n_tiles, p.tiles_per_group);
-  p.per_image_logits = sdg_align((size_t)kT * p.ldl * sizeof(float));
+  p.per_image_logits = logits24 ? sdg_align((size_t)(p.ldl / 128) * kTileBytes24, 1024)     // 24-bit tiles + references
+                                : sdg_align((size_t)kT * p.ldl * sizeof(float));
   p.per_image_partial = sdg_align((size_t)p.n_groups * kT * 2 * sizeof(float));
   p.per_image_stats = sdg_align((size_t)kT * 2 * sizeof(float));
   p.per_image_scores = sdg_align((size_t)p.ldl * sizeof(float));
@@ -1306,6 +1307,13 @@ int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* id
 size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk) {
   if (batch < 1) batch = 1;
   const ScorePlan p = score_plan(r, batch, topk);
+  return p.topk_bytes + (size_t)batch * p.per_image();
+}
+
+size_t sixdgs_score_topk_workspace_bytes_ex(int64_t r, int batch, int topk, int mma_mode, int with_key_planes) {
+  if (batch < 1) batch = 1;
+  const bool l24 = with_key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_DEFAULT);
+  const ScorePlan p = score_plan(r, batch, topk, l24);
   return p.topk_bytes + (size_t)batch * p.per_image();
 }
 
@@ -1354,7 +1362,7 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
   SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
   SDG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)ws % 256) == 0);
   hipStream_t s = sdg_stream(stream);
-  ScorePlan p = score_plan(r, batch, topk);
+  ScorePlan p = score_plan(r, batch, topk, use_f16 && logits24);
   const size_t per_image = p.per_image();
   // largest image group whose logits + top-k scratch fit the caller's workspace
   int64_t bg = batch > 65535 ? 65535 : batch;

@@ -356,7 +356,11 @@ def q_proj(tokens: torch.Tensor, n_tok: torch.Tensor, weights: PackedWeights) ->
     return q
 
 
-def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100) -> int:
+def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100, planes: bool = False) -> int:
+    """Workspace of the scorer for `batch` resident images.  planes=True: the call will run on pre-split key planes in the
+    active MMA mode (24-bit logits in MMA_F16X3: 23 % smaller); False: enough for every mode."""
+    if planes:
+        return int(_lib.load().sixdgs_score_topk_workspace_bytes_ex(int(r), int(batch), int(topk), effective_mma_mode(), 1))
     return int(_lib.load().sixdgs_score_topk_workspace_bytes(int(r), int(batch), int(topk)))
 
 
@@ -378,7 +382,7 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
     stats = torch.empty(b, MAX_TOKENS, 2, device=dev) if want_stats else None
     if workspace is None:
         inflight = b if images_in_flight is None else max(1, min(b, images_in_flight))
-        workspace = torch.empty(score_topk_workspace_bytes(r, inflight, topk), dtype=torch.uint8, device=dev)
+        workspace = torch.empty(score_topk_workspace_bytes(r, inflight, topk, planes=key_planes is not None), dtype=torch.uint8, device=dev)
     h_n = None
     if profile is not None and n_tok_host is not None:
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])

@@ -115,9 +115,9 @@ def main():
     else:
         free_b = torch.cuda.mem_get_info(dev)[0]
         inflight = args.batch
-        while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100) > 0.6 * free_b:
+        while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100, planes=True) > 0.6 * free_b:
             inflight -= 1
-    ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100), dtype=torch.uint8, device=dev)
+    ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------

@@ -232,7 +232,9 @@ int sixdgs_q_proj(const float* tokens, const int32_t* d_n_tok, int batch,
 /* scores[b][r] = sum_t softmax_r(q[b][t] . key[r] / sqrt(384)); idx/val = top-k (sorted
  * descending, ties -> lowest index).  scores may be NULL (then they live only in the workspace).
  * Never materialises more than `ws` allows: images are processed in groups that fit. */
-size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk);
+size_t sixdgs_score_topk_workspace_bytes(int64_t r, int batch, int topk);   /* enough for every mode */
+/* exact for a mode: with key planes in F16X3 / DEFAULT the logits take 784 instead of 1024 B per ray and image */
+size_t sixdgs_score_topk_workspace_bytes_ex(int64_t r, int batch, int topk, int mma_mode, int with_key_planes);
 int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, int batch, const float* key /*[R,384]*/,
                       int64_t r, int topk, float* scores /*[B,R] or NULL*/, int64_t* idx /*[B,topk]*/,
                       float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,

@@ -65,8 +65,10 @@ def test_scorer_invariants_at_full_size(full):
     R = ori.shape[0]
     assert R > 31_000_000
     _, _, (planes, inv) = ops.ray_keys(ori, dr, rgb, full["w"], want_key=False, want_planes=True)
-    ws = torch.empty(ops.score_topk_workspace_bytes(R, 2, 100), dtype=torch.uint8, device="cuda")
-    idx, val, sc, st = ops.score_topk(q, n_tok, None, 100, want_stats=True, workspace=ws, key_planes=planes, key_scale=inv)
+    small, large = ops.score_topk_workspace_bytes(R, 2, 100, planes=True), ops.score_topk_workspace_bytes(R, 2, 100)
+    assert small < 0.8 * large                                     # 24-bit logits: 784 instead of 1024 B per ray and image
+    ws = torch.empty(large, dtype=torch.uint8, device="cuda")     # (the bf16x6 comparison below needs the fp32-logits size)
+    idx, val, sc, st = ops.score_topk(q, n_tok, None, 100, want_stats=True, workspace=ws[:small], key_planes=planes, key_scale=inv)
     # softmax mass: every token row sums to 1 over the rays -> the scores of an image sum to its token count
     tot = sc.double().sum(dim=1).cpu().numpy()
     assert np.allclose(tot, n_tok.cpu().numpy(), rtol=2e-4)
