@@ -1053,6 +1053,7 @@ __global__ void __launch_bounds__(256) k_score_reduce_blocked24(const float* __r
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned score_key(float v) {
   unsigned u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0u;          // -0.0 == +0.0: one key, so that the tie goes to the lower index
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float key_score(unsigned k) {

@@ -527,3 +527,69 @@ def test_solve_pose_batched_equals_single(ops, golden):
     for i, n in enumerate(names):
         assert np.abs(N(out["c2w"])[i] - g[f"{n}_c2w"]).max() < 1e-5
     assert np.isnan(N(out["errors"])).all()               # no ground truth given
+
+
+def test_topk_randomised_against_the_oracle(ops, oracle):
+    """Radix select + ordered gather + bitonic sort against the oracle's (value desc, index asc) rule on 40 random shapes:
+    heavy ties, all-equal rows, +-inf, signed zeros, sizes around the block / pass boundaries, k from 1 to 1024."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        r = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 65537, 300001]))
+        k = int(rng.choice([1, 7, 100, 256, 1024]))
+        kind = trial % 5
+        if kind == 0:
+            s = rng.standard_normal((2, r))
+        elif kind == 1:
+            s = rng.integers(-3, 4, size=(2, r)).astype(np.float64)             # heavy ties, both zeros' signs below
+        elif kind == 2:
+            s = np.full((2, r), 0.25)
+        elif kind == 3:
+            s = rng.standard_normal((2, r)) * 1e-30                              # denormal-ish magnitudes
+        else:
+            s = rng.standard_normal((2, r))
+            s[0, rng.integers(0, r, size=min(r, 5))] = np.inf
+            s[1, rng.integers(0, r, size=min(r, 5))] = -np.inf
+        s = s.astype(np.float32)
+        if kind == 1:
+            s[0, ::3] *= np.float32(-1.0)                                         # -0.0 among the zeros: equal to +0.0
+        idx, val = ops.topk(G(s), k)
+        for b in range(2):
+            oi, ov = oracle.topk(s[b], k)
+            n = min(k, r)
+            assert (N(idx)[b, :n] == oi[:n]).all(), (trial, r, k, kind)
+            assert (N(val)[b, :n] == ov[:n]).all() and (N(idx)[b, n:] == -1).all()
+
+
+def test_pose_tail_randomised_against_the_oracle(ops, oracle):
+    """a17-a21 on 60 random top-k sets (duplicate origins in varying multiplicity, rays behind the centre, 3 <= k <= 100):
+    kept-ray count, status flags, centre, final weights and c2w against the oracle (itself pinned by the g6 goldens)."""
+    rng = np.random.default_rng(77)
+    R = 500
+    for trial in range(60):
+        k = int(rng.choice([3, 5, 8, 17, 37, 100]))
+        c = rng.standard_normal(3).astype(np.float32) * 2
+        ori = rng.standard_normal((R, 3)).astype(np.float32)
+        dr = c[None] - ori + rng.standard_normal((R, 3)).astype(np.float32) * 0.05
+        dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+        flip = rng.random(R) < 0.15
+        dr[flip] *= -1                                                  # camera behind those rays
+        n_dup = int(rng.integers(0, 4))
+        for _ in range(n_dup):                                          # duplicated origins (several rays of one ellipsoid point)
+            a, b = rng.integers(0, R, size=2)
+            ori[b] = ori[a]
+        idx = rng.choice(R, size=k, replace=False).astype(np.int64)
+        w = np.sort(rng.random(k).astype(np.float32))[::-1].copy()
+        up = rng.standard_normal(3).astype(np.float32)
+        up /= np.linalg.norm(up)
+        out = ops.solve_pose(G(ori), G(dr), G(idx)[None], G(w)[None], G(up)[None])
+        o = oracle.pose_from_topk(ori, dr, idx, w, up)
+        assert int(out["n_kept"][0]) == o["n_kept"], trial
+        st = int(out["status"][0])
+        assert bool(st & 1) == bool(o["flags"][0]) and bool(st & 2) == bool(o["flags"][1]), trial
+        if np.isnan(o["centre"]).any():
+            assert st & 4
+            continue
+        scale = max(1.0, float(np.abs(o["c2w"]).max()))
+        assert np.abs(N(out["centre"])[0] - o["centre"]).max() <= 2e-4 * scale, trial     # 3x3 solves of near-parallel ray bundles
+        assert np.abs(N(out["w_final"])[0] - o["w_final"]).max() < 1e-6, trial
+        assert np.abs(N(out["c2w"])[0] - o["c2w"]).max() <= 2e-4 * scale, trial
