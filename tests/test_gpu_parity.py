@@ -593,3 +593,49 @@ def test_pose_tail_randomised_against_the_oracle(ops, oracle):
         assert np.abs(N(out["centre"])[0] - o["centre"]).max() <= 2e-4 * scale, trial     # 3x3 solves of near-parallel ray bundles
         assert np.abs(N(out["w_final"])[0] - o["w_final"]).max() < 1e-6, trial
         assert np.abs(N(out["c2w"])[0] - o["c2w"]).max() <= 2e-4 * scale, trial
+
+
+def test_geometry_randomised_against_the_oracle(ops, oracle):
+    """Wide-range random inputs for the integer-valued geometry rows: validity mask and ring / cell counts on ellipsoids whose
+    axes span 1e-4 .. 1e2 with strong anisotropy (a2, a6), closed-form eigen-decomposition of random, nearly degenerate and
+    exactly degenerate symmetric matrices (a5), iso-cell distributions for 20 targets (a8)."""
+    rng = np.random.default_rng(99)
+    # a2 / a6: scales log-uniform over six decades
+    scale = np.exp(rng.uniform(np.log(1e-4), np.log(1e2), size=(600, 3))).astype(np.float32)
+    for P in (17, 50, 64):
+        m = N(ops.mask_degraded(G(np.log(scale)), P))
+        act = np.exp(np.log(scale).astype(np.float32)).astype(np.float32)
+        ref = oracle.mask_degraded(act, P)
+        assert (m != ref).sum() <= 2                                   # exp(log s) on the GPU may differ from the host's by an ulp
+        ok = ref & m
+        sub = act[ok][:200]
+        pts, eid = ops.quadricell_centers(G(sub), P)
+        opts, oeid = oracle.quadricell_centers(sub, P)
+        assert pts.shape[0] == opts.shape[0] and (N(eid) == oeid).all()   # identical ring and cell counts for every ellipsoid
+        d = np.abs(N(pts) - opts).max(1) / sub[oeid].max(1)
+        assert np.quantile(d, 0.98) < 1e-5                              # the rest: table ties (conftest.quadricell_tie_cells)
+    # a5: random symmetric, near-degenerate (two close eigenvalues), exactly diagonal, rank one
+    a = rng.standard_normal((300, 3, 3))
+    mats = [a @ a.transpose(0, 2, 1)]
+    q, _ = np.linalg.qr(rng.standard_normal((100, 3, 3)))
+    lam = np.stack([np.ones(100), 1 + 1e-6 * rng.random(100), 3 * np.ones(100)], 1)
+    mats.append(q @ (lam[:, :, None] * q.transpose(0, 2, 1)))
+    mats.append(np.stack([np.diag(v) for v in rng.random((50, 3))]))
+    v = rng.standard_normal((50, 3, 1))
+    mats.append(v @ v.transpose(0, 2, 1))
+    mats = np.concatenate(mats).astype(np.float32)
+    vals, vecs = ops.sym_eig_3x3(G(mats))
+    ov, oe = oracle.sym_eig_3x3(mats)
+    sc = np.abs(ov).max(1, keepdims=True) + 1e-30
+    assert (np.abs(N(vals) - ov) / sc).max() < 5e-5
+    w = np.linalg.eigvalsh(mats.astype(np.float64))
+    assert (np.abs(np.sort(N(vals), axis=1) - w) / sc).max() < 2e-4     # and they ARE the eigenvalues
+    gap = np.minimum(ov[:, 1] - ov[:, 0], ov[:, 2] - ov[:, 1]) / sc[:, 0]
+    ok = gap > 1e-2
+    assert np.abs(N(vecs)[ok] - oe[ok]).max() < 5e-3
+    # a8: iso-cell directions
+    for tgt in (1, 2, 3, 7, 10, 16, 35, 50, 64, 100, 128, 200, 256, 300, 500, 777, 1000, 1024, 2048, 4096):
+        for n0 in (1, 3):
+            d = N(ops.isocell_distribution(tgt, n0))
+            od = oracle.isocell_distribution(tgt, n0)
+            assert d.shape == od.shape and np.abs(d - od).max() < 2e-6, (tgt, n0)
