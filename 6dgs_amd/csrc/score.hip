@@ -522,9 +522,10 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   const bool active = wm * 64 < M;
   float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
   float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
-  // A.n_tiles / A.tiles_per_group count 256-ray tiles here
-  const int t_begin = grp * A.tiles_per_group;
-  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
+  // A.n_tiles counts 256-ray tiles here; the groups take floor(n_tiles / n_groups) tiles, the first n_tiles % n_groups one more
+  const int t_base = A.n_tiles / A.n_groups, t_rem = A.n_tiles - t_base * A.n_groups;
+  const int t_begin = grp * t_base + min(grp, t_rem);
+  const int t_end = t_begin + t_base + (grp < t_rem ? 1 : 0);
   const int n_tiles128 = (int)((A.r + 127) >> 7);
   if (M > 0 && t_begin < t_end) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
@@ -1411,9 +1412,9 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
           int n_groups_x = 1024;
           while (n_groups_x > 256 && n_tiles_x / n_groups_x < 16) n_groups_x -= 256;
           if (n_groups_x > p.n_groups) n_groups_x = p.n_groups;
-          const int tpg_x = (int)sdg_cdiv(n_tiles_x, n_groups_x);
-          n_groups_used = (int)sdg_cdiv(n_tiles_x, tpg_x);
-          V.tiles_per_group = tpg_x;
+          if (n_groups_x > n_tiles_x) n_groups_x = n_tiles_x;
+          n_groups_used = n_groups_x;             // exactly this many runs (a whole number of rounds of the 256 CUs), lengths differ by <= 1
+          V.tiles_per_group = (int)sdg_cdiv(n_tiles_x, n_groups_x);
           V.n_tiles = n_tiles_x;
           V.n_groups = n_groups_used;
           auto kern = logits24 ? k_logits_f16x<0, true> : k_logits_f16x<0, false>;
