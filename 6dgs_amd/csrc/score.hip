@@ -1,14 +1,18 @@
 // score.hip -- the per-image part of the scorer:
-//   logits[t][r] = q[t] . key[r] / sqrt(384)           (fp32 MFMA tile kernel, stores + row stats)
-//   score[r]     = sum_t exp(logits[t][r] - max_t) / sumexp_t      (HBM-streaming reduce)
+//   logits[t][r] = q[t] . key[r] / sqrt(384)           (matrix-core tile kernels, stored once + online row statistics)
+//   score[r]     = sum_t exp(logits[t][r] - max_t) / sumexp_t      (HBM-streaming second pass)
 //   top-k        = radix select over the score bits + ordered gather + small sort
 // replaces MultiHeadAttention.forward (our_multihead_attention.py:70-79,4-12), the column sum of
 // IdentificationModule.run_attention (identification_module.py:80-82) and torch.topk (:131).
 //
-// The softmax runs over the RAY axis (rows = image tokens): its row statistics must be complete
-// before any column sum can be formed, so the [T, R] logits are written once to a caller-provided
-// workspace (1 KB per ray and image, token-major) instead of recomputing the contraction in a second
-// pass: at R = 32 M that is 64 GB of extra HBM traffic (~12 ms) against ~40 ms of fp32 MFMA work.
+// The softmax runs over the RAY axis (rows = image tokens): its row statistics must be complete before any column sum can
+// be formed, so the [T, R] logits are written once to a caller-provided workspace and streamed back, instead of recomputing
+// the contraction in a second pass.  Three logits kernels, selected by SIXDGS_MMA_* (include/sixdgs.h):
+//   k_logits_f16x   (default)  scaled fp16 planes x 3 MFMA terms, 256 x 256 tiles, 24-bit (or fp32) blocked logits
+//   k_logits_v2     BF16X6 on pre-split bf16 planes, 128 x 128 tiles, fp32 token-major logits
+//   k_logits<MMA>   fp32 keys: fp32 MFMA chain (F32) or bf16 x 6 with the split done on the fly
+// followed by k_merge_stats, k_score_reduce(_blocked, _blocked24) and the top-k kernels.  DESIGN.md 3a / 3b tell how the
+// default kernel got its shape and what bounds it.
 #include <stdlib.h>
 
 #include "gemm_kernel.h"
