@@ -128,6 +128,9 @@ def test_a24_test_pose_estimation(pkg, e2e):
         assert r["frame_id"] == i and r["sequence_id"] == "seq" and r["category_name"] == "cat"
     assert abs(te - float(g["e2e_mean_terr"])) < 1e-4 * max(1.0, float(g["e2e_mean_terr"]))
     assert abs(ae - float(g["e2e_mean_aerr"])) < 1e-2
+    import json                                     # the driver stores the list with json.dump (pretrain_eval_attention.py:246-248)
+    back = json.loads(json.dumps(res))
+    assert len(back) == n and np.array(back[0]["pred_c2w"]).shape == (4, 4) and back[0]["frame_id"] == 0
 
 
 def test_a24_loss_fn_branch(pkg, e2e, golden):
