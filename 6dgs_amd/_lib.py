@@ -20,6 +20,7 @@ sz = C.c_size_t
 
 
 PROFILE_SLOTS = 128
+ABI_VERSION = 2          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
 
 
 class Profile(C.Structure):
@@ -103,8 +104,8 @@ def load():
             raise RuntimeError(f"6dgs_amd: {LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sixdgs_abi_version() != 2:
-        raise RuntimeError("6dgs_amd: ABI version mismatch")
+    if lib.sixdgs_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"6dgs_amd: ABI version mismatch (library {lib.sixdgs_abi_version()}, binding {ABI_VERSION})")
     _lib = lib
     return lib
 

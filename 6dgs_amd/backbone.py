@@ -14,6 +14,7 @@ module exposing forward_features(x)["x_norm_patchtokens"].
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import Optional
 
@@ -145,7 +146,12 @@ def create_backbone(type="dino", backbone: Optional[torch.nn.Module] = None, **k
             if isinstance(proj, torch.nn.Conv2d):
                 proj.__class__ = _PatchConv          # same parameters, GEMM evaluation
         except Exception as e:  # offline: no network, no cache
-            warnings.warn(f"DINOv2 weights unavailable ({e.__class__.__name__}); using a randomly initialised ViT-S/14")
+            # The reference fails here (backbone.py:15).  A randomly initialised ViT gives meaningless tokens, so it is only
+            # substituted on explicit request (tests, bench.py and smoke() set the variable: no weights can be downloaded there).
+            if os.environ.get("SIXDGS_RANDOM_BACKBONE", "0") != "1":
+                raise RuntimeError(f"6dgs_amd: DINOv2 ViT-S/14 weights unavailable ({e.__class__.__name__}: {e}); pass backbone=<module> "
+                                   "or set SIXDGS_RANDOM_BACKBONE=1 to run with a randomly initialised ViT-S/14 (benchmarks/tests only)") from e
+            warnings.warn(f"DINOv2 weights unavailable ({e.__class__.__name__}); SIXDGS_RANDOM_BACKBONE=1: randomly initialised ViT-S/14")
             backbone = ViTS14()
     return backbone, (16, 16), 384
 
@@ -237,10 +243,18 @@ class BackboneWrapper(torch.nn.Module):
 
     @staticmethod
     def get_img_position_encoding(img_features_shape, freqs, dtype=torch.float32, device="cpu"):
-        """backbone.py:116-139: [pos(2), sin(2*freqs), cos(2*freqs)] on linspace(-1,1)^2."""
-        grids = [torch.linspace(-1.0, 1.0, steps=s, dtype=dtype, device=device) for s in img_features_shape]
-        positions = torch.stack(torch.meshgrid(*grids, indexing="ij"), dim=-1).reshape(-1, len(grids))
-        freq_bands = (2 ** torch.arange(freqs).float()).to(positions.device)
-        pts = (positions[..., None] * freq_bands).reshape(positions.shape[:-1] + (freqs * positions.shape[-1],))
-        pts = torch.cat([positions, torch.sin(pts), torch.cos(pts)], dim=-1)
-        return pts.reshape(*img_features_shape, pts.shape[-1])
+        """The 2 + 4*freqs grid channels appended to every patch token (semantics of backbone.py:116-139): per cell of the
+        h x w token grid its (row, col) coordinate u in [-1,1]^2, then sin(u_a * 2^f) for axis-major / octave-minor (a, f),
+        then the cosines in the same order.  Built as one outer product per axis and broadcast over the grid -- the table is
+        tiny (16 x 16 x 14) and cached per (dtype, device) by position_encoding()."""
+        h, w = img_features_shape
+        octave = torch.exp2(torch.arange(freqs, dtype=torch.float32, device=device))
+        axis_u = (torch.linspace(-1.0, 1.0, steps=h, dtype=dtype, device=device), torch.linspace(-1.0, 1.0, steps=w, dtype=dtype, device=device))
+        out = torch.empty(h, w, 2 + 4 * freqs, dtype=dtype, device=device)
+        for a, u in enumerate(axis_u):
+            view = (h, 1) if a == 0 else (1, w)
+            out[..., a] = u.view(*view)
+            phase = (u[:, None] * octave).view(*view, freqs)                    # [h,1,F] or [1,w,F]
+            out[..., 2 + a * freqs: 2 + (a + 1) * freqs] = torch.sin(phase)
+            out[..., 2 + (2 + a) * freqs: 2 + (3 + a) * freqs] = torch.cos(phase)
+        return out

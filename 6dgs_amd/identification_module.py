@@ -82,6 +82,7 @@ class IdentificationModule(torch.nn.Module):
         self._packed_key = None
         self._key_cache = None
         self._key_cache_id = None
+        self._key_cache_rays = None
 
     # ---- caches -------------------------------------------------------------------------------------
     def _scorer_params(self):
@@ -108,9 +109,15 @@ class IdentificationModule(torch.nn.Module):
 
     def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None):
         w = self.packed_weights(rays_ori.device)
-        ident = (rays_ori.data_ptr(), rays_dir.data_ptr(), rays_rgb.data_ptr(), rays_ori.shape[0], rays_ori._version,
-                 rays_dir._version, rays_rgb._version, self._packed_key, ops.effective_mma_mode())
-        if self._key_cache is None or self._key_cache_id != ident:
+        # Identity of the cache entry: the three ray tensor OBJECTS (held strongly, so the allocator cannot hand their
+        # addresses to a new ray set while the entry lives), their in-place versions, the weights and the MMA mode.
+        ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, ops.effective_mma_mode())
+        held = self._key_cache_rays
+        same = (self._key_cache is not None and self._key_cache_id == ident and held is not None
+                and all(h is t or (h.data_ptr() == t.data_ptr() and h.shape == t.shape and h.stride() == t.stride())   # a view of
+                        for h, t in zip(held, (rays_ori, rays_dir, rays_rgb))))       # the held (hence still allocated) memory
+        if not same:
+            self._key_cache = self._key_cache_rays = None        # drop the old planes before allocating the new ones
             r = rays_ori.shape[0]
             mode = ops.effective_mma_mode()
             planes_mode = mode != ops.MMA_F32
@@ -124,6 +131,7 @@ class IdentificationModule(torch.nn.Module):
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
                 planes = None
             self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale}, ident
+            self._key_cache_rays = (rays_ori, rays_dir, rays_rgb)
         return self._key_cache
 
     def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
@@ -147,7 +155,9 @@ class IdentificationModule(torch.nn.Module):
         return c[:b]
 
     def invalidate_caches(self):
-        self._packed = self._key_cache = None
+        """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
+        that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
+        self._packed = self._key_cache = self._key_cache_rays = None
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()

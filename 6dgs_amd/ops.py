@@ -42,14 +42,33 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+_call_device = None      # device of the tensors of the call being marshalled (set by _need_gpu, read by _stream)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current PyTorch stream OF THE TENSORS' DEVICE (not of whatever device is current in the process)."""
+    dev = _call_device if _call_device is not None else torch.cuda.current_device()
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _need_gpu(*ts):
+    """Every tensor argument must be a GPU tensor, all on ONE device; that device is made current for the launch (the
+    kernels run on the device that is current when the library is entered) and its current stream is the one passed."""
+    global _call_device
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("6dgs_amd: tensors must live on the GPU (no CPU fallback on the product path)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"6dgs_amd: tensor arguments on different devices ({dev} and {t.device})")
+    if dev is not None:
+        _call_device = dev.index
+        if torch.cuda.current_device() != dev.index:
+            torch.cuda.set_device(dev)
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -173,6 +192,7 @@ def isocell_distribution(ray_target: int, n0: int = 1, device="cuda") -> torch.T
     cnt = C.c_int64(0)
     check(lib.sixdgs_isocell_distribution(int(ray_target), int(n0), None, C.byref(cnt), _stream()), "isocell_distribution")
     out = torch.empty(cnt.value, 3, device=device)
+    _need_gpu(out)
     check(lib.sixdgs_isocell_distribution(int(ray_target), int(n0), _p(out), C.byref(cnt), _stream()), "isocell_distribution")
     return out
 

@@ -29,6 +29,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")   # synthetic benchmark: random-init ViT-S/14 (no network for the DINOv2 weights)
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (same table); the logits kernel spends 6 bf16 MFMA terms per

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")     # no DINOv2 weights can be downloaded here: the tests opt in to a random ViT-S/14
 
 
 def pytest_configure(config):

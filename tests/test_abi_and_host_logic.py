@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/sixdgs.h but not exported"
     L = importlib.import_module("6dgs_amd._lib")
     assert set(L.SIGNATURES) == set(syms), set(L.SIGNATURES) ^ set(syms)
-    assert L.load().sixdgs_abi_version() == 2
+    ge = importlib.import_module("__graft_entry__")
+    assert L.load().sixdgs_abi_version() == L.ABI_VERSION == ge.header_abi_version()
+    ge.post_build_checks()       # the checks build() ends with: they must pass on the built tree (round-1 bug: a stale literal)
     # argument errors are reported without touching the GPU
     assert L.load().sixdgs_mask_degraded(None, -1, 50, None, None) == -1
     assert b"bad argument" in L.load().sixdgs_error_string(-1)

@@ -1,5 +1,7 @@
 """Where one bench step goes, phase by phase (HIP events around the phases of test.estimate_poses)."""
 import importlib, os, sys, time
+import os
+os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
