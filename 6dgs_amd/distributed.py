@@ -123,6 +123,21 @@ def barrier():
         dist.barrier()
 
 
+def backend_name() -> str:
+    """"nccl" (= RCCL on ROCm) / "gloo" when a process group is up, "none" for a single process."""
+    return dist.get_backend() if is_dist() else "none"
+
+
+def ranks_seen(device) -> int:
+    """How many ranks take part in the collectives: an all-reduce (sum) of ones over the process group -- over RCCL on
+    device memory when the backend is nccl.  1 without a process group."""
+    if not is_dist():
+        return 1
+    one = torch.ones(1, dtype=torch.float32, device=device if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
 def max_over_ranks(x: float, device) -> float:
     if not is_dist():
         return x

@@ -111,7 +111,9 @@ class IdentificationModule(torch.nn.Module):
         w = self.packed_weights(rays_ori.device)
         # Identity of the cache entry: the three ray tensor OBJECTS (held strongly, so the allocator cannot hand their
         # addresses to a new ray set while the entry lives), their in-place versions, the weights and the MMA mode.
-        ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, ops.effective_mma_mode())
+        mode = ops.effective_mma_mode()
+        fmt = "f32" if mode == ops.MMA_F32 else ("f16-planes" if mode in ops.F16_MODES else "bf16-planes")   # F16X3 / F16X3_L32 share planes
+        ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, fmt)
         held = self._key_cache_rays
         same = (self._key_cache is not None and self._key_cache_id == ident and held is not None
                 and all(h is t or (h.data_ptr() == t.data_ptr() and h.shape == t.shape and h.stride() == t.stride())   # a view of
@@ -119,7 +121,6 @@ class IdentificationModule(torch.nn.Module):
         if not same:
             self._key_cache = self._key_cache_rays = None        # drop the old planes before allocating the new ones
             r = rays_ori.shape[0]
-            mode = ops.effective_mma_mode()
             planes_mode = mode != ops.MMA_F32
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
             scale = None
@@ -205,7 +206,8 @@ class IdentificationModule(torch.nn.Module):
         return idx, val, scores
 
     @torch.no_grad()
-    def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608):
+    def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608,
+                              profile=None):
         """The scorer without a resident key cache, for ray sets whose keys (1536 B/ray) plus logits (1 KB/ray/image) exceed
         the GPU: the rays go through in chunks and every chunk's keys are computed, used and dropped -- twice, because the
         softmax runs over ALL rays: sweep 1 collects each chunk's row statistics and merges them (M = max m_c,
@@ -216,8 +218,10 @@ class IdentificationModule(torch.nn.Module):
         w = self.packed_weights(dev)
         if torch.is_tensor(token_list):
             tokens, n_tok = token_list.contiguous(), self._full_ntok(token_list.shape[0], dev)
+            n_host = [tokens.shape[1]] * tokens.shape[0]
         else:
             tokens, n_tok = ops.pad_tokens(token_list, dev)
+            n_host = [int(t.shape[0]) for t in token_list]
         q = ops.q_proj(tokens, n_tok, w)
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
         chunk = max(128, (min(chunk_rays, max(r, 1)) + 127) // 128 * 128)       # whole fp16 scale tiles
@@ -229,10 +233,10 @@ class IdentificationModule(torch.nn.Module):
             o, d, c = rays_ori[r0:r1].contiguous(), rays_dir[r0:r1].contiguous(), rays_rgb[r0:r1].contiguous()
             if ops.effective_mma_mode() == ops.MMA_F32:
                 _, key = ops.ray_keys(o, d, c, w)
-                return ops.score_pass1(q, n_tok, key, ws, k), r1 - r0, False
+                return ops.score_pass1(q, n_tok, key, ws, k, profile=profile, n_tok_host=n_host), r1 - r0, False
             _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
             planes, scale = planes if f16 else (planes, None)
-            return ops.score_pass1(q, n_tok, None, ws, k, key_planes=planes, key_scale=scale), r1 - r0, True
+            return ops.score_pass1(q, n_tok, None, ws, k, key_planes=planes, key_scale=scale, profile=profile, n_tok_host=n_host), r1 - r0, True
 
         m_g = torch.full((b, ops.MAX_TOKENS), -float("inf"), device=dev)
         s_g = torch.zeros(b, ops.MAX_TOKENS, device=dev)

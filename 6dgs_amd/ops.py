@@ -418,7 +418,8 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
 
 
 def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], workspace: torch.Tensor, topk: int = 100,
-                key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None,
+                profile: Optional["KernelProfile"] = None, n_tok_host=None) -> torch.Tensor:
     """First half of the ray-sharded scorer (include/sixdgs.h: sixdgs_score_pass1): logits of this shard for all images
     stay in `workspace` (score_topk_workspace_bytes(r, batch, topk) bytes); returns the shard's row statistics [B,256,2]."""
     q = _f32(q)
@@ -427,8 +428,10 @@ def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor
     r = key.shape[0] if key is not None else key_planes.shape[0]
     b = q.shape[0]
     stats = torch.empty(b, MAX_TOKENS, 2, device=q.device)
-    check(_lib.load().sixdgs_score_pass1(_p(q), _p(n_tok), None, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(stats),
-                                         _p(workspace), workspace.numel(), _stream(), None, _mma_mode), "score_pass1")
+    h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if (profile is not None and n_tok_host is not None) else None
+    check(_lib.load().sixdgs_score_pass1(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(stats),
+                                         _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,
+                                         _mma_mode), "score_pass1")
     return stats
 
 

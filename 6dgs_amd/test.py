@@ -125,11 +125,13 @@ def prime_image_graph(id_module, images) -> bool:
 
 @torch.no_grad()
 def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
-                   images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False, image_graph: bool = True):
+                   images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False, image_graph: bool = True,
+                   streamed_chunk_rays: Optional[int] = None):
     """One batch of the hot path: query images (uint8 [H,W,3|4] tensors on the GPU) -> poses.
     image prep -> backbone tokens + camera-up (PyTorch-ROCm) -> q_proj / scorer / top-k / pose solve (HIP).
     `tokens` / `up` inject the image-side boundary inputs instead.  Everything is enqueued on the current
-    stream; nothing syncs until the caller reads the returned device tensors."""
+    stream; nothing syncs until the caller reads the returned device tensors.  `streamed_chunk_rays` selects the
+    streamed scorer (IdentificationModule.score_tokens_streamed) with that chunk size."""
     if tokens is None:
         res = None
         if image_graph and not torch.cuda.is_current_stream_capturing():
@@ -141,8 +143,13 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
             imgs_f, masks = prepare_images_device(images)
             tokens, fmaps = id_module.image_tokens(imgs_f, masks)
             up = id_module.camera_up(fmaps)
-    idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
-                                                  workspace=workspace, images_in_flight=images_in_flight, profile=profile)
+    if streamed_chunk_rays:       # no resident key cache: ray chunks through ray MLP + scorer (scenes beyond one GPU's HBM)
+        idx, weights = id_module.score_tokens_streamed(tokens, rays_ori, rays_dirs, rays_rgb, k, chunk_rays=int(streamed_chunk_rays),
+                                                       profile=profile)
+        scores = None
+    else:
+        idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
+                                                      workspace=workspace, images_in_flight=images_in_flight, profile=profile)
     sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt_c2w)
     sol.update(idx=idx, weights=weights, scores=scores, tokens=tokens, up=up)
     return sol

@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- poses/sec of the MI355X-native 6DGS pose path on BASELINE.json's headline workload.
+"""bench.py -- poses/sec of the MI355X-native 6DGS pose path on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--config headline|cfg1|cfg2|cfg3|cfg4]
 
-Workload (config.workload): synthetic 500 k-Gaussian scene (SURVEY.md §8(d) generator, seed 0), rays
-emitted from EVERY valid Gaussian with the iso-cell emitter at 64 rays per ellipsoid (R = 32.0 M rays),
-800x800 uint8 query images, `--batch` images per GPU per step.  One step = one pass of the hot path over
-one batch: image prep -> ViT-S/14 tokens + camera-up CNN (PyTorch-ROCm, random init: DINOv2 weights are
-not downloadable) -> q_proj -> ray<->token scorer over the cached fp32 keys -> top-100 -> pose solve ->
-c2w on the host.  Scene set-up (normals, emission, ray MLP + k_proj key cache) happens once per scene,
-as in the reference (pretrain_eval_attention.py:89), and is reported separately.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or started plainly -- then bench.py
+re-launches itself under torch.distributed.run on 127.0.0.1 with a free port (one process per GPU over RCCL).
 
-Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize, max over
-ranks; value = (N * batch * K) / time.  Images and scene arrays are resident in HBM when the clock starts.
-Rank 0 prints ONE JSON line with `roofline` (the logits kernel: algorithmic FLOP / HIP-event time) and,
-at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded ray sample, all host cores).
+Workload (config.workload).  `--config headline` (default) is the configuration BASELINE.json's metric is quoted on:
+synthetic 500 k-Gaussian scene (SURVEY.md §8(d) generator, seed 0), rays emitted from EVERY valid Gaussian with the
+iso-cell emitter at 64 rays per ellipsoid (R = 32.0 M rays), 800x800 uint8 query images, 4 images per GPU per step.
+The other presets are BASELINE.json's `configs` entries (sizes per SURVEY.md §8), each image-sharded over the ranks:
+  cfg1  10 k Gaussians x 64 rays, one 400x400 query                     (configs[0]; the reference's CPU-runnable case)
+  cfg2  300 k Gaussians read back from a 3DGS PLY, x 64 rays, one query  (configs[1])
+  cfg3  1 M Gaussians x 64 = 64 M rays, 8 images per GPU                  (configs[2]: 64 views over 8 GPUs)
+  cfg4  2 M Gaussians x 256 = 512 M rays, 16 images per GPU, key cache does not fit: streamed scorer   (configs[3])
+One step = one pass of the hot path over one batch: image prep -> ViT-S/14 tokens + camera-up CNN (PyTorch-ROCm,
+random init: DINOv2 weights are not downloadable) -> q_proj -> ray<->token scorer over the cached key planes -> top-100
+-> pose solve -> c2w on the host.  Scene set-up (normals, emission, ray MLP + k_proj key cache) happens once per
+scene, as in the reference (pretrain_eval_attention.py:89), and is reported separately.
+
+Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize, max over ranks;
+value = (N * batch * K) / time.  Every step ends with the poses on the host, so the K per-step wall times are exact
+too: their median is reported beside the mean (`median_step`).  Images and scene arrays are resident
+in HBM when the clock starts.  Rank 0 prints ONE JSON line with `roofline` (the logits kernel: algorithmic FLOP /
+HIP-event time), `fp32_logits_mode` (the same workload with the logits kept in fp32 between the passes instead of
+24-bit fixed point: the cost of not narrowing) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded ray sample).
 """
 from __future__ import annotations
 
@@ -22,31 +33,48 @@ import argparse
 import importlib
 import json
 import os
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")   # synthetic benchmark: random-init ViT-S/14 (no network for the DINOv2 weights)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (same table); the logits kernel spends 6 bf16 MFMA terms per
-                                # fp32 product, so its roofline in ALGORITHMIC (fp32-equivalent) FLOP/s is 2500 / 6
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X dense bf16/fp16 MFMA peak (same table); a logits kernel that spends n 16-bit MFMA terms
+                                 # per fp32 product has the roofline 2500 / n in ALGORITHMIC (fp32-equivalent) FLOP/s
+
+PRESETS = {
+    #            Gaussians  rays/ellipsoid  images/GPU/step  query size  scene source        scorer
+    "headline": dict(gaussians=500_000, rays_per_ellipsoid=64, batch=4, image_size=800, scene="synthetic", scoring="resident"),
+    "cfg1": dict(gaussians=10_000, rays_per_ellipsoid=64, batch=1, image_size=400, scene="synthetic", scoring="resident"),
+    "cfg2": dict(gaussians=300_000, rays_per_ellipsoid=64, batch=1, image_size=800, scene="ply", scoring="resident"),
+    "cfg3": dict(gaussians=1_000_000, rays_per_ellipsoid=64, batch=8, image_size=800, scene="synthetic", scoring="resident"),
+    "cfg4": dict(gaussians=2_000_000, rays_per_ellipsoid=256, batch=16, image_size=800, scene="synthetic", scoring="streamed"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 1 for cfg4)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="query images per GPU per step")
-    ap.add_argument("--gaussians", type=int, default=500_000)
-    ap.add_argument("--rays-per-ellipsoid", type=int, default=64)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="headline", help="BASELINE.json workload preset (see the module docstring)")
+    ap.add_argument("--batch", type=int, default=None, help="query images per GPU per step (overrides the preset)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--rays-per-ellipsoid", type=int, default=None)
+    ap.add_argument("--image-size", type=int, default=None)
+    ap.add_argument("--scene", choices=["synthetic", "ply"], default=None,
+                    help="ply: the synthetic scene is written as a 3DGS point_cloud.ply and read back through GaussianScene.load_ply")
+    ap.add_argument("--scoring", choices=["resident", "streamed"], default=None,
+                    help="resident: key planes cached in HBM (1536 B/ray); streamed: ray chunks whose keys are computed, used and dropped")
+    ap.add_argument("--chunk-rays", type=int, default=8_388_608, help="streamed scorer: rays per chunk")
     ap.add_argument("--mode", choices=["full", "reference"], default="full",
                     help="full: every Gaussian, iso-cell emitter (headline); reference: 1000-ellipsoid quadricell subsample")
-    ap.add_argument("--image-size", type=int, default=800)
     ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f16x3l32", "f32"], default="default",
                     help="matrix-core scheme of the logits kernel (default = the library's default mode)")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -54,14 +82,37 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole per-batch path (image prep, ViT, CNN, scorer, pose solve) in one hipGraph and replay it "
                          "per step: for the launch-bound small-scene regime (--mode reference); kernel timing needs the eager path")
+    ap.add_argument("--l32-steps", type=int, default=-1,
+                    help="steps of the secondary fp32-logits measurement (-1 = min(steps, 3) when the main mode is f16x3; 0 = skip)")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in PRESETS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.steps is None:
+        args.steps = 1 if args.scoring == "streamed" else 5
+    return args
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher -- one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve) on a free port."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import torch
     pkg = importlib.import_module("6dgs_amd")
     syn = importlib.import_module("6dgs_amd.synthetic")
     dd = importlib.import_module("6dgs_amd.distributed")
@@ -75,16 +126,26 @@ def main():
     if forced_dev is not None:
         local = int(forced_dev)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
+    ranks_seen = dd.ranks_seen(dev)          # an all-reduce of ones over the process group (RCCL when world > 1)
 
     # ---- scene: rank 0 owns it, RCCL broadcast of the Gaussian arrays, local re-emission ------------------
     t_setup = time.time()
-    scene = pkg.GaussianScene.from_dict(syn.make_scene(args.gaussians, 0), device=dev) if rank == 0 else None
+    scene = None
+    if rank == 0:
+        scene = pkg.GaussianScene.from_dict(syn.make_scene(args.gaussians, 0), device=dev)
+        if args.scene == "ply":                # the on-disk format either side of the path: 3DGS point_cloud.ply (gaussian_model.py:284-420)
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "point_cloud", "iteration_30000", "point_cloud.ply")
+                scene.save_ply(path)
+                scene = pkg.GaussianScene.load_ply(path, sh_degree=3, device=dev)
     scene = dd.broadcast_scene(scene, 0, device=dev)
     idm = pkg.IdentificationModule("dino")
     idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
@@ -98,27 +159,31 @@ def main():
         finite = torch.isfinite(dr).all(dim=1)   # normals exactly (anti)parallel to z give NaN rays (isocell.py:208-212)
         if not bool(finite.all()):
             ori, dr, rgb = ori[finite].contiguous(), dr[finite].contiguous(), rgb[finite].contiguous()
+        del finite
     else:
         ori, dr, rgb = pkg.generate_all_possible_rays(scene)
     torch.cuda.synchronize()
     t_emit = time.time() - t0
     R = int(ori.shape[0])
+    streamed = args.scoring == "streamed"
     kprof = ops.KernelProfile()
     t0 = time.time()
-    idm._ensure_keys(ori, dr, rgb, profile=kprof)
-    torch.cuda.synchronize()
+    ws, inflight, k_ms, k_fl = None, args.batch, 0.0, 0.0
+    if not streamed:
+        idm._ensure_keys(ori, dr, rgb, profile=kprof)
+        torch.cuda.synchronize()
+        k_ms, k_fl, _, _ = kprof.collect()
     t_keys = time.time() - t0
-    k_ms, k_fl, _, _ = kprof.collect()
-    # images whose [256, R] logits are resident at once (they share every key tile through L2): --in-flight, or as many
-    # of the batch as fit in 60 % of the free HBM (1 KB per ray and image: 4 x 32.8 GB at R = 32 M next to 49 GB of keys)
-    if args.in_flight > 0:
-        inflight = min(args.in_flight, args.batch)
-    else:
-        free_b = torch.cuda.mem_get_info(dev)[0]
-        inflight = args.batch
-        while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100, planes=True) > 0.6 * free_b:
-            inflight -= 1
-    ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
+    if not streamed:
+        # images whose [256, R] logits are resident at once (they share every key tile through L2): --in-flight, or as many
+        # of the batch as fit in 60 % of the free HBM (784 B per ray and image next to the 1536 B/ray key planes)
+        if args.in_flight > 0:
+            inflight = min(args.in_flight, args.batch)
+        else:
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100, planes=True) > 0.6 * free_b:
+                inflight -= 1
+        ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------
@@ -131,12 +196,16 @@ def main():
 
     graph, graph_sol = None, None
 
+    def run_batch(p):
+        return tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p,
+                                 streamed_chunk_rays=args.chunk_rays if streamed else None)
+
     def step(p):
         if graph is not None:
             graph.replay()
             sol = graph_sol
         else:
-            sol = tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p)
+            sol = run_batch(p)
         c2w, st = dd.gather_poses(sol["c2w"], sol["status"], 0)
         host = (c2w if c2w is not None else sol["c2w"]).cpu()   # all poses on the host = end of the step
         return host, sol
@@ -149,61 +218,96 @@ def main():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=None)
+            run_batch(None)
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            graph_sol = tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=None)
+            graph_sol = run_batch(None)
         graph = g
+
+    def timed(n_steps, p):
+        """exactly n_steps steps bracketed by barrier + synchronize; (max-over-ranks seconds, per-step seconds, last results)"""
+        torch.cuda.synchronize()
+        dd.barrier()
+        per, t_begin = [], time.perf_counter()
+        for _ in range(n_steps):
+            t1 = time.perf_counter()
+            host, s = step(p)
+            per.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        dd.barrier()
+        return dd.max_over_ranks(time.perf_counter() - t_begin, dev), per, s
 
     for _ in range(args.warmup):
         step(None)
-    torch.cuda.synchronize()
-    dd.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        host_poses, sol = step(None if args.graph else prof)
-    torch.cuda.synchronize()
-    dd.barrier()
-    elapsed = dd.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
     l_ms, l_fl, l_by, l_n = prof.collect()
+
+    mode = ops.effective_mma_mode()
+    mma_name = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3", ops.MMA_F16X3_L32: "f16x3l32"}
+    # ---- the same workload with fp32 logits between the two scorer passes (VERDICT r1: keep the cost of not narrowing visible)
+    l32 = None
+    n32 = (min(args.steps, 3) if args.l32_steps < 0 else args.l32_steps) if (mode == ops.MMA_F16X3 and not args.graph) else 0
+    if n32 > 0:
+        ops.set_mma_mode(ops.MMA_F16X3_L32)          # same key planes (the cache is keyed on the plane format), 1024 instead of
+        step(None)                                   # 784 B of logits per ray and image: the library regroups the images in `ws`
+        e32, per32, _ = timed(n32, None)
+        ops.set_mma_mode(ops.MMA_DEFAULT if args.mma == "default" else ops.MMA_F16X3)
+        l32 = {"mma": "f16x3l32", "value": round(world * args.batch * n32 / e32, 4), "unit": "poses/s", "steps": n32,
+               "ms_per_step": round(1e3 * e32 / n32, 3),
+               "note": "logits between the scorer passes as fp32 (1024 B/ray/image) instead of 24-bit fixed point (784 B): no intermediate below fp32"}
 
     poses = world * args.batch * args.steps
     value = poses / elapsed
+    med = statistics.median(per_step)
     out = {
         "metric": "poses/sec", "value": round(value, 4), "unit": "poses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "median_step": {"ms": round(1e3 * med, 3), "poses_per_s": round(world * args.batch / med, 4), "n": len(per_step),
+                        "min_ms": round(1e3 * min(per_step), 3), "max_ms": round(1e3 * max(per_step), 3),
+                        "note": "rank-0 wall time of each timed step (every step ends with the poses on the host)"},
         "arithmetic": ("fp32 results; q.K^T as 2 power-of-two-scaled fp16 planes x 3 MFMA terms, dense layers as 3 bf16 planes x 6 MFMA "
-                       "terms, fp32 accumulation (measured error <= that of the fp32 MFMA chain)"),
+                       "terms, fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
+                       + ("; logits travel between the two scorer passes as 24-bit fixed point, absolute error <= 2^-20 per logit "
+                          "(fp32_logits_mode = the same run without that narrowing)" if mode == ops.MMA_F16X3 else "")),
         "config": {
-            "workload": (f"synthetic {args.gaussians}-Gaussian scene, "
+            "workload": (f"{args.config}: synthetic {args.gaussians}-Gaussian scene" + (" (through a 3DGS PLY file)" if args.scene == "ply" else "") + ", "
                          + (f"iso-cell emission from every valid Gaussian x {args.rays_per_ellipsoid} rays" if args.mode == "full"
                             else "reference-mode quadricell emission from 1000 sampled ellipsoids")
                          + f" (R={R} rays), {args.image_size}x{args.image_size} uint8 queries, 256 tokens x 384, top-100, "
                          f"{args.batch} images/GPU/step; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
-            "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
+            "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch,
+            "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
             "parallelism": f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)",
+            "mma": mma_name[mode],
         },
+        "ranks_seen": ranks_seen, "backend": dd.backend_name(),
         "errors_vs_synthetic_gt": {"mean_translation": float(sol["errors"][:, 0].mean()), "mean_angular_deg": float(sol["errors"][:, 1].mean()),
                                    "note": "random-init weights: accuracy is not meaningful, parity is tested in tests/"},
         "scene_setup_s": {"total": round(t_setup, 3), "normals+emission": round(t_emit, 3), "ray_mlp_keys": round(t_keys, 3),
                           "ray_mlp_keys_tflops": round(k_fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None},
     }
+    if streamed:
+        out["config"]["chunk_rays"] = args.chunk_rays
+        out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj "
+                                         "and the scorer twice (row statistics, then scores + top-k merge); nothing of size R x 384 is resident")
+    if l32 is not None:
+        out["fp32_logits_mode"] = l32
     if rank == 0:
-        mode = ops.effective_mma_mode()
-        out["config"]["mma"] = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3", ops.MMA_F16X3_L32: "f16x3l32"}[mode]
-        traffic = None
+        traffic, traffic_source = None, None
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
                 if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("%s -- builder's separate rocprofv3 --pmc pass over this same command (round %s), NOT measured in this run"
+                                      % (tj.get("source", os.path.relpath(args.traffic_json, ROOT)), tj.get("round")))
             except Exception:
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0
         terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3, ops.MMA_F16X3_L32: 3}[mode]
-        peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_BF16_MFMA_TFLOPS / terms
+        peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_16BIT_MFMA_TFLOPS / terms
         out["roofline"] = {
             "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
                                        "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
@@ -217,7 +321,7 @@ def main():
             "peak_basis": "157.3 TFLOP/s dense fp32 MFMA" if mode == ops.MMA_F32 else
                           ("2500 TFLOP/s dense 16-bit MFMA / %d MFMA terms per fp32 product; achieved = algorithmic 2*T*384 FLOP per "
                            "ray and image / HIP-event time (executed 16-bit MFMA rate = %dx achieved)" % (terms, terms)),
-            "achieved_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "achieved_vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "launches": l_n, "avg_launch_ms": round(l_ms / max(l_n, 1), 4),
             "algorithmic_flop_per_launch": l_fl / max(l_n, 1), "algorithmic_bytes_per_launch": l_by / max(l_n, 1),
             "share_of_step_time": round(l_ms * 1e-3 / elapsed, 4),
@@ -236,6 +340,7 @@ def cpu_baseline(args, idm, ori, dr, rgb, R, sol):
     """The CPU oracle (oracle/sixdgs_oracle.c, OpenMP, all host cores) on a bounded sample of the same workload:
     the per-pose path (q_proj, 3-pass softmax scorer, top-100, pose tail) over the first `cpu_sample_rays` rays
     of the scene with the SAME keys, extrapolated linearly in R (the scorer is linear in R)."""
+    import torch
     from oracle import oracle as O
     O.build()
     rs = int(min(args.cpu_sample_rays, R))

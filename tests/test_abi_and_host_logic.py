@@ -177,3 +177,19 @@ def test_ply_ingestion_follows_the_reference_layout(tmp_path):
         assert torch.equal(getattr(s, k), getattr(s3, k)), k
     with pytest.raises(RuntimeError):
         pkg.GaussianScene.load_ply(p1, 2, device="cpu")                    # wrong SH degree (gaussian_model.py:368)
+
+
+def test_bench_plain_multi_gpu_start_becomes_the_launcher():
+    """`python bench.py --gpus 2` without a rank environment must re-launch itself under torch.distributed.run (a plain
+    start used to SystemExit before any rank existed).  No GPU here: the two ranks must get as far as the "needs an MI355X" exit,
+    which proves the launcher ran and handed RANK / WORLD_SIZE to bench.py."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SIXDGS_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--gaussians", "100"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_bench_contract.py")
+    assert p.returncode != 0
+    assert "needs an MI355X" in p.stderr and "WORLD_SIZE=1" not in p.stderr, p.stderr[-1500:]

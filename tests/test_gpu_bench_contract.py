@@ -41,6 +41,7 @@ def test_bench_single_gpu_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["ranks_seen"] == 1 and d["median_step"]["n"] == 2 and d["config"]["preset"] == "headline"
 
 
 @pytest.mark.timeout(500)
@@ -52,3 +53,41 @@ def test_bench_two_ranks_code_path():
              env={"SIXDGS_BENCH_BACKEND": "gloo", "SIXDGS_BENCH_FORCE_DEVICE": "0"})
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d       # baseline only on rank 0 at N = 1
     assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]   # whole-job aggregate over both ranks
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo"
+
+
+@pytest.mark.timeout(500)
+def test_bench_plain_start_self_launches_the_ranks():
+    """`python bench.py --gpus 2` with no rank environment (how the driver may start the scaling runs): bench.py becomes the
+    launcher itself.  One GPU here, so the two ranks share it over gloo (test hooks); on the 8-GPU node the same path runs
+    one rank per GPU over RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SIXDGS_BENCH_BACKEND="gloo", SIXDGS_BENCH_FORCE_DEVICE="0")
+    p = subprocess.run([sys.executable, "-W", "ignore", "bench.py", "--gpus", "2", "--gaussians", "8000", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+
+
+@pytest.mark.timeout(600)
+def test_bench_presets_cfg1_cfg2_and_streamed_scorer():
+    """BASELINE.json configs as bench presets: cfg1 (10 k Gaussians, one 400x400 query), cfg2's code path (scene through a 3DGS
+    PLY file, one query; size reduced here, the full 300 k run is tests/test_gpu_configs.py) and cfg4's streamed scorer at a
+    small size."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run([sys.executable, "-W", "ignore", "bench.py", "--config", "cfg1", "--steps", "5", "--skip-cpu-baseline"])
+    assert d["config"]["preset"] == "cfg1" and d["config"]["gaussians"] == 10_000 and d["config"]["images_per_gpu_per_step"] == 1
+    assert d["median_step"]["n"] == 5 and d["median_step"]["min_ms"] <= d["median_step"]["ms"] <= d["median_step"]["max_ms"]
+    assert d["fp32_logits_mode"]["mma"] == "f16x3l32" and d["fp32_logits_mode"]["value"] > 0
+    assert "traffic_source" in d["roofline"]
+    d = _run([sys.executable, "-W", "ignore", "bench.py", "--config", "cfg2", "--gaussians", "20000", "--steps", "2", "--skip-cpu-baseline"])
+    assert d["config"]["preset"] == "cfg2" and "PLY" in d["config"]["workload"] and d["config"]["images_per_gpu_per_step"] == 1
+    d = _run([sys.executable, "-W", "ignore", "bench.py", "--config", "cfg4", "--gaussians", "4000", "--batch", "3", "--chunk-rays", "300000",
+              "--steps", "1", "--skip-cpu-baseline"])
+    assert d["config"]["scoring"] == "streamed" and d["config"]["rays"] == 4000 * 256 and d["roofline"]["launches"] >= 8
