@@ -207,13 +207,16 @@ class IdentificationModule(torch.nn.Module):
 
     @torch.no_grad()
     def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608,
-                              profile=None):
-        """The scorer without a resident key cache, for ray sets whose keys (1536 B/ray) plus logits (1 KB/ray/image) exceed
-        the GPU: the rays go through in chunks and every chunk's keys are computed, used and dropped -- twice, because the
-        softmax runs over ALL rays: sweep 1 collects each chunk's row statistics and merges them (M = max m_c,
-        S = sum s_c e^(m_c - M)), sweep 2 recomputes the chunk, finishes it with the global statistics and merges its top-k
-        candidates (value descending, global index ascending).  Same result as score_tokens up to the rounding of the sum of
-        exponentials; costs two ray-MLP and two logits passes.  Returns (idx [B,k], val [B,k]); no [B,R] score vector."""
+                              profile=None, key_cache_bytes: Optional[int] = None, return_stats: bool = False):
+        """The scorer without a resident key cache, for ray sets whose keys (1536 B/ray) plus logits (784 B/ray/image) exceed
+        the GPU: the rays go through in chunks, ALL images of the batch share each chunk's keys, and the keys are computed,
+        used and dropped -- twice, because the softmax runs over ALL rays: sweep 1 collects each chunk's row statistics and
+        merges them (M = max m_c, S = sum s_c e^(m_c - M)), sweep 2 finishes every chunk with the global statistics and merges
+        its top-k candidates (value descending, global index ascending).  The key planes of as many chunks as fit in
+        `key_cache_bytes` (default: 70 % of the HBM that is free once the logits workspace exists) survive from sweep 1 to
+        sweep 2, so only the remaining chunks pay the ray MLP twice.  Same result as score_tokens up to the rounding of the sum
+        of exponentials.  Returns (idx [B,k], val [B,k]); no [B,R] score vector.  return_stats: also (global row statistics
+        [B,256,2], softmax mass per image = sum of all scores, which must equal the image's token count)."""
         dev = rays_ori.device
         w = self.packed_weights(dev)
         if torch.is_tensor(token_list):
@@ -225,23 +228,38 @@ class IdentificationModule(torch.nn.Module):
         q = ops.q_proj(tokens, n_tok, w)
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
         chunk = max(128, (min(chunk_rays, max(r, 1)) + 127) // 128 * 128)       # whole fp16 scale tiles
-        ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k), dtype=torch.uint8, device=dev)
-        f16 = ops.effective_mma_mode() in ops.F16_MODES
+        mode = ops.effective_mma_mode()
+        f16, planes_mode = mode in ops.F16_MODES, mode != ops.MMA_F32
+        ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), dtype=torch.uint8, device=dev)
+        if key_cache_bytes is None:
+            key_cache_bytes = int(0.7 * torch.cuda.mem_get_info(dev)[0])
+        kept, kept_bytes = {}, 0                                                  # r0 -> key operand of the chunk, sweep 1 -> sweep 2
 
-        def chunk_pass1(r0):
+        def chunk_keys(r0, may_keep):
+            nonlocal kept_bytes
+            if r0 in kept:
+                return kept.pop(r0)
             r1 = min(r0 + chunk, r)
-            o, d, c = rays_ori[r0:r1].contiguous(), rays_dir[r0:r1].contiguous(), rays_rgb[r0:r1].contiguous()
-            if ops.effective_mma_mode() == ops.MMA_F32:
+            o, d, c = rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1]             # row slices of contiguous [R,3]: contiguous views
+            if not planes_mode:
                 _, key = ops.ray_keys(o, d, c, w)
-                return ops.score_pass1(q, n_tok, key, ws, k, profile=profile, n_tok_host=n_host), r1 - r0, False
-            _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
-            planes, scale = planes if f16 else (planes, None)
-            return ops.score_pass1(q, n_tok, None, ws, k, key_planes=planes, key_scale=scale, profile=profile, n_tok_host=n_host), r1 - r0, True
+                ent, nbytes = (key, None, None), key.numel() * 4
+            else:
+                _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
+                planes, scale = planes if f16 else (planes, None)
+                ent, nbytes = (None, planes, scale), planes.numel()
+            if may_keep and kept_bytes + nbytes <= key_cache_bytes:
+                kept[r0], kept_bytes = ent, kept_bytes + nbytes
+            return ent
+
+        def chunk_pass1(r0, may_keep):
+            key, planes, scale = chunk_keys(r0, may_keep)
+            return ops.score_pass1(q, n_tok, key, ws, k, key_planes=planes, key_scale=scale, profile=profile, n_tok_host=n_host)
 
         m_g = torch.full((b, ops.MAX_TOKENS), -float("inf"), device=dev)
         s_g = torch.zeros(b, ops.MAX_TOKENS, device=dev)
         for r0 in range(0, r, chunk):                        # sweep 1: statistics
-            st, _, _ = chunk_pass1(r0)
+            st = chunk_pass1(r0, True)
             m_c, s_c = st[..., 0], st[..., 1]
             m_n = torch.maximum(m_g, m_c)
             safe = torch.where(torch.isinf(m_n), torch.zeros_like(m_n), m_n)
@@ -251,12 +269,17 @@ class IdentificationModule(torch.nn.Module):
         glob = torch.stack([m_g, s_g], dim=-1).contiguous()
         best_i = torch.full((b, k), -1, dtype=torch.int64, device=dev)
         best_v = torch.full((b, k), float("nan"), device=dev)
+        mass = torch.zeros(b, dtype=torch.float64, device=dev)
         from . import distributed as dd
         for r0 in range(0, r, chunk):                        # sweep 2: scores of the chunk, candidate merge
-            _, rl, planes_used = chunk_pass1(r0)
-            idx, val, _ = ops.score_pass2(glob, n_tok, rl, ws, k, used_planes=planes_used, want_scores=False)
+            chunk_pass1(r0, False)
+            idx, val, sc = ops.score_pass2(glob, n_tok, min(r0 + chunk, r) - r0, ws, k, used_planes=planes_mode, want_scores=return_stats)
+            if return_stats:
+                mass += sc.double().sum(dim=1)
             gi = torch.where(idx >= 0, idx + r0, idx)
             best_i, best_v = dd.merge_topk(torch.cat([best_i, gi], dim=1), torch.cat([best_v, val], dim=1), 0, k, group=False)
+        if return_stats:
+            return best_i, best_v, glob, mass
         return best_i, best_v
 
     @torch.no_grad()
