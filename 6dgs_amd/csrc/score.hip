@@ -464,7 +464,16 @@ struct LogitsF16Args {
   float* partial;
   int64_t r, ldl;
   int tiles_per_group, n_tiles, n_groups, b0, nb;
+  // OUT == kOutUB only (top-k without materialised logits, see "select path" below)
+  const float* ctok;     // [B][256] per-token exponent offset: -ref_t log2e - log2(f Z~_t), -inf for tokens >= n_tok
+  float* ub;             // [nb][4 token quarters wm][ub_stride] partial upper-bound sums of every ray
+  int64_t ub_stride;
 };
+// what the kernel leaves behind for each tile
+constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
+constexpr int kOutL24 = 1;     // logits as 24-bit fixed point + running (max, sumexp)
+constexpr int kOutStats = 2;   // running (max, sumexp) only (the sample pre-pass of the select path)
+constexpr int kOutUB = 3;      // per ray: sum_t exp(l_tr - ref_t) / (f Z~_t) (4 token-quarter partials); per token: the exact sum over rays
 
 // A wave-uniform global load through the scalar cache.  As a plain load hipcc emits global_load_dword (the kernel also
 // stores to global memory, so it cannot prove the location unclobbered) followed by s_waitcnt vmcnt(0) -- which drains
@@ -511,9 +520,11 @@ constexpr int kQStageX = 256 * 64;       // one plane of one stage
 constexpr int kKBaseX = 4 * kQStageX;    // 64 KiB
 constexpr int kLdsX = kKBaseX + 6 * kQStageX;   // 160 KiB
 
-// L24: the logits leave the kernel as 24-bit fixed point instead of fp32 (see kTileBytes24 below)
-template <int ABL, bool L24>
+// OUT: what leaves the kernel (kOut*): fp32 or 24-bit fixed-point logits (see kTileBytes24), statistics only, or the
+// upper-bound column sums of the select path
+template <int ABL, int OUT>
 __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
+  constexpr bool L24 = OUT == kOutL24;
   __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   const int bl = (int)(w % (unsigned)A.nb), grp = (int)(w / (unsigned)A.nb);
@@ -526,6 +537,11 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   const bool active = wm * 64 < M;
   float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
   float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  float ct[2] = {0.f, 0.f}, zs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (OUT == kOutUB) {
+    ct[0] = A.ctok[(int64_t)b * kT + wm * 64 + (lane & 31)];
+    ct[1] = A.ctok[(int64_t)b * kT + wm * 64 + 32 + (lane & 31)];
+  }
   // A.n_tiles counts 256-ray tiles here; the groups take floor(n_tiles / n_groups) tiles, the first n_tiles % n_groups one more
   const int t_base = A.n_tiles / A.n_groups, t_rem = A.n_tiles - t_base * A.n_groups;
   const int t_begin = grp * t_base + min(grp, t_rem);
@@ -720,7 +736,69 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       // ---- epilogue.  Lane l holds token (l & 31) and, per accumulator register group rg, the four consecutive rays
       // 8 rg + 4 (l >> 5) + {0..3} of its 32-ray block: one 16-byte store per group, 1 KiB contiguous per wave instruction.
       // The constant undoes both power-of-two operand scales (exactly) and applies 1/sqrt 384.
-      if (active) {
+      if (OUT == kOutUB) {
+        // ---- select path.  e'[t][r] = exp2(acc * cfl + ct[t]) = exp(logit - ref_t) / (f Z~_t); the per-token sums over the rays
+        // accumulate in zs (exact softmax denominators relative to ref_t); the per-ray sums over this wave's 64 tokens are formed
+        // by a halving butterfly over the 32 lanes of each half wave (lane bit i <-> ray-register bit 3 - i, DPP for the two
+        // in-quad steps, ds_swizzle for the rest) and leave as TWO 4-byte stores per lane and tile: ray
+        // 64 b4 + 32 x + 8 rg + 4 h + j of the wave's 128-ray half with 4 rg + j = bitrev4(lane & 15), h = lane >> 5.
+        if (active) {
+          const int t128 = min(2 * tile + wn, n_tiles128 - 1);
+          const float cfl = ((cq * load_uniform(A.kinv + t128)) * kInvSqrtD) * 1.4426950408889634f;
+          const bool ragged = lim_cur < kBNX - 1;
+          const int ray0 = wn * 128 + 4 * (lane >> 5);
+          const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8, lb4 = lane & 16;
+          float fin[4];
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            float u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[0][tn][r], cfl, ct[0]));
+              float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[1][tn][r], cfl, ct[1]));
+              if (ragged) {
+                const bool ok = ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur;   // clamped duplicates of the last ray
+                e0 = ok ? e0 : 0.f;
+                e1 = ok ? e1 : 0.f;
+              }
+              zs[0][r & 3] += e0;
+              zs[1][r & 3] += e1;
+              u[r] = e0 + e1;
+            }
+            float v8[8], v4[4], v2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float keep = lb0 ? u[i + 8] : u[i], send = lb0 ? u[i] : u[i + 8];
+              v8[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float keep = lb1 ? v8[i + 4] : v8[i], send = lb1 ? v8[i] : v8[i + 4];
+              v4[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float keep = lb2 ? v4[i + 2] : v4[i], send = lb2 ? v4[i] : v4[i + 2];
+              v2[i] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x101F));   // lane ^ 4
+            }
+            {
+              const float keep = lb3 ? v2[1] : v2[0], send = lb3 ? v2[0] : v2[1];
+              fin[tn] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x201F));   // lane ^ 8
+            }
+          }
+          float o[2];
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            const float keep = lb4 ? fin[2 + x] : fin[x], send = lb4 ? fin[x] : fin[2 + x];
+            o[x] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));      // lane ^ 16
+          }
+          const int rrev = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+          const int inhalf = ((lane & 16) << 2) + 8 * (rrev >> 2) + 4 * (lane >> 5) + (rrev & 3);
+          float* up = A.ub + ((int64_t)bl * 4 + wm) * A.ub_stride + ((int64_t)tile * kBNX + wn * 128 + inhalf);
+          __builtin_nontemporal_store(o[0], up);
+          __builtin_nontemporal_store(o[1], up + 32);
+        }
+      } else if (active) {
         const int t128 = min(2 * tile + wn, n_tiles128 - 1);
         const float cf = (cq * load_uniform(A.kinv + t128)) * kInvSqrtD;
         float* tb = lg + (int64_t)(2 * tile + wn) * (kT * 128);
@@ -741,7 +819,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
               acc[tm][tn][4 * rg + 1] = v.y;
               acc[tm][tn][4 * rg + 2] = v.z;
               acc[tm][tn][4 * rg + 3] = v.w;
-              if (!L24 && !(ABL & 64)) {
+              if (OUT == kOutF32 && !(ABL & 64)) {
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(tb + tm * 4096 + tn * 1024 + rg * 256));
               }
@@ -804,8 +882,13 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     float* pp = part[wn * 2 + (lane >> 5)][wm * 64 + tm * 32 + (lane & 31)];
-    pp[0] = m_run[tm];
-    pp[1] = s_run[tm];
+    if (OUT == kOutUB) {     // sums relative to the fixed reference: merged as (max 0, sum)
+      pp[0] = 0.f;
+      pp[1] = (zs[tm][0] + zs[tm][1]) + (zs[tm][2] + zs[tm][3]);
+    } else {
+      pp[0] = m_run[tm];
+      pp[1] = s_run[tm];
+    }
   }
   __syncthreads();
   if (tid < 256) {
@@ -1219,6 +1302,216 @@ __global__ void __launch_bounds__(1024) k_topk_sort(const unsigned* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Select path: the top-k WITHOUT the [T, R] logits ever reaching HBM (inference: no score vector is asked for).
+//   score[r] = sum_t e[t][r] / Z_t,  e = exp(logit - ref_t),  Z_t = sum_r e[t][r].
+// A pre-pass over a 1/f ray sample gives ref_t (the sample maximum) and Z~_t (so that f Z~_t ~ Z_t).  The main sweep forms
+//   U[r] = sum_t e[t][r] / (f Z~_t)   (4 B per ray and image instead of 784)   and the EXACT   g_t = Z_t / (f Z~_t),
+// so that score[r] = sum_t e'[t][r] / g_t lies in [U[r] / g_max, U[r] / g_min].  Every ray of the true top-k therefore has
+// U[r] >= U_(k) g_min / g_max (U_(k) = k-th largest U): those few rays are re-scored exactly from their key planes and the
+// top-k of the exact scores is the result -- the sample only decides how many candidates there are, never the answer.
+// ------------------------------------------------------------------------------------------------
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ctok[b][t] = -ref_t log2e - log2(f Z~_t)   (-inf for padding tokens: their e' is exactly 0)
+__global__ void __launch_bounds__(kT) k_sel_prepare(const float* __restrict__ stats_s, const int* __restrict__ n_tok, int b0, float log2_frac,
+                                                    float* __restrict__ ctok) {
+  const int bl = blockIdx.x, t = threadIdx.x;
+  const float m = stats_s[((int64_t)bl * kT + t) * 2], z = stats_s[((int64_t)bl * kT + t) * 2 + 1];
+  const bool ok = t < n_tok[b0 + bl] && z > 0.f && m > -INFINITY && m < INFINITY;
+  ctok[(int64_t)bl * kT + t] = ok ? -(m * kLog2e) - (log2f(z) + log2_frac) : -INFINITY;
+}
+
+// U[bl][r] = sum of the token-quarter partials that exist (waves whose 64 tokens are all padding write nothing)
+__global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub, int64_t stride, const int* __restrict__ n_tok, int b0, int64_t R,
+                                                    float* __restrict__ U) {
+  const int bl = blockIdx.y;
+  const int nq = (n_tok[b0 + bl] + 63) >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= R) return;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nq; ++w) {
+    const float4 v = *reinterpret_cast<const float4*>(ub + ((int64_t)bl * 4 + w) * stride + i);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(U + (int64_t)bl * stride + i) = a;     // stride is a multiple of 256: the tail past R is scratch
+}
+
+// per image: g_min / g_max over its tokens, the candidate threshold on U and the validity of the bounds.
+// info[bl][4] = {threshold on U, flag, -, -}: flag 0 ok, 1 = no tokens (all scores are exactly 0), 2 = bounds unusable (overflow / NaN)
+__global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ stats_g, const int* __restrict__ n_tok, int b0, const float* __restrict__ valU,
+                                                   int topk, int k_eff, float* __restrict__ info, float* __restrict__ rg) {
+  __shared__ float smin[4], smax[4];
+  const int bl = blockIdx.x, t = threadIdx.x, M = n_tok[b0 + bl];
+  const float g = stats_g[((int64_t)bl * kT + t) * 2 + 1];
+  rg[(int64_t)bl * kT + t] = (t < M && g > 0.f) ? 1.f / g : 0.f;
+  float lo = t < M ? g : INFINITY, hi = t < M ? g : -INFINITY;
+  bool bad = t < M && !(g > 0.f && g < INFINITY);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  const unsigned long long anybad = __ballot(bad);
+  if (sdg_lane() == 0) { smin[sdg_wave()] = anybad ? NAN : lo; smax[sdg_wave()] = hi; }
+  __syncthreads();
+  if (t == 0) {
+    float flag = 0.f, thr = INFINITY;
+    if (M <= 0) flag = 1.f;
+    else {
+      float a = smin[0], b = smax[0];
+      bool nan = a != a;
+      for (int w = 1; w < 4; ++w) { nan = nan || smin[w] != smin[w]; a = fminf(a, smin[w]); b = fmaxf(b, smax[w]); }
+      const float uk = valU[(int64_t)bl * topk + (k_eff - 1)];
+      if (nan || !(uk >= 0.f && uk < INFINITY) || !(a > 0.f)) flag = 2.f;
+      else thr = uk * (a / b) * 0.99998474f;      // (1 - 2^-16): fp32 rounding of U (256-term sums) and of the exact re-score
+    }
+    info[bl * 4 + 0] = thr;
+    info[bl * 4 + 1] = flag;
+  }
+}
+
+// ordered compaction of {r : U[r] >= threshold}: COUNT -> counts[bl][blk]; WRITE -> cand[bl][pos] = r in ascending r for pos < cmax
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_sel_candidates(const float* __restrict__ U, int64_t stride, int64_t R, const float* __restrict__ info,
+                                                        int64_t span, unsigned* __restrict__ counts, const unsigned* __restrict__ offs,
+                                                        int64_t* __restrict__ cand, int cmax) {
+  __shared__ int sc[4];
+  const int bl = blockIdx.y;
+  const float thr = info[bl * 4 + 0];
+  const float* u = U + (int64_t)bl * stride;
+  const int64_t i0 = (int64_t)blockIdx.x * span, i1 = min(i0 + span, R);
+  unsigned run = 0;
+  const unsigned base = WRITE ? offs[(int64_t)bl * gridDim.x + blockIdx.x] : 0u;
+  for (int64_t c0 = i0; c0 < i1; c0 += 256) {
+    const int64_t i = c0 + threadIdx.x;
+    const bool in = i < i1 && u[i] >= thr;
+    const unsigned long long bm = __ballot(in);
+    const int lane = sdg_lane(), wv = sdg_wave();
+    if (lane == 0) sc[wv] = __popcll(bm);
+    __syncthreads();
+    unsigned before = 0, tot = 0;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (w2 < wv) before += sc[w2];
+      tot += sc[w2];
+    }
+    __syncthreads();
+    if (WRITE && in) {
+      const unsigned pos = base + run + before + __popcll(bm & ((1ull << lane) - 1ull));
+      if (pos < (unsigned)cmax) cand[(int64_t)bl * cmax + pos] = i;
+    }
+    run += tot;
+  }
+  if (!WRITE && threadIdx.x == 0) counts[(int64_t)bl * gridDim.x + blockIdx.x] = run;
+}
+
+// exclusive scan of the per-block candidate counts; total[bl] = number of candidates
+__global__ void __launch_bounds__(1024) k_sel_scan(const unsigned* __restrict__ counts, int nb, unsigned* __restrict__ offs, int* __restrict__ total) {
+  __shared__ unsigned sm[17];
+  const int bl = blockIdx.x;
+  unsigned base = 0;
+  for (int c0 = 0; c0 < nb; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const unsigned v = i < nb ? counts[(int64_t)bl * nb + i] : 0u;
+    unsigned tot;
+    const unsigned ex = sdg_block_exclusive_scan<unsigned, 16>(v, sm, &tot);
+    if (i < nb) offs[(int64_t)bl * nb + i] = base + ex;
+    base += tot;
+  }
+  if (threadIdx.x == 0) total[bl] = (int)min(base, 0x7fffffffu);
+}
+
+// exact scores of the candidates: 8 candidates per block, thread t = token t.  The same operands as the matrix-core kernel
+// (scaled fp16 planes, three cross terms) accumulated with fp32 FMAs.
+__global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp, const float* __restrict__ qinv, const char* __restrict__ kp,
+                                                    const float* __restrict__ kinv, const int* __restrict__ n_tok, int b0,
+                                                    const float* __restrict__ ctok, const float* __restrict__ rg, const int64_t* __restrict__ cand,
+                                                    const int* __restrict__ total, int cmax, int compact, float* __restrict__ cscore) {
+  __shared__ __attribute__((aligned(16))) char krow[8][kRowF];
+  __shared__ float kscale[8];
+  __shared__ float red[8][4];
+  const int bl = blockIdx.y, b = b0 + bl, t = threadIdx.x;
+  const int n = min(total[bl], cmax);
+  const int c0 = blockIdx.x * 8;
+  if (c0 >= n) {
+    if (t < 8 && c0 + t < cmax) cscore[(int64_t)bl * cmax + c0 + t] = -INFINITY;
+    return;
+  }
+  const int nc = min(8, n - c0);
+  for (int i = t; i < 8 * (kRowF / 16); i += kT) {
+    const int c = i / (kRowF / 16), o = i - c * (kRowF / 16);
+    // compact: kp holds the planes of this image's candidates in candidate order ([nb][cmax] rows, own 128-row tile scales)
+    const int64_t r = compact ? (int64_t)bl * cmax + c0 + min(c, nc - 1) : cand[(int64_t)bl * cmax + c0 + min(c, nc - 1)];
+    reinterpret_cast<float4*>(krow[c])[o] = reinterpret_cast<const float4*>(kp + r * kRowF)[o];
+    if (o == 0) kscale[c] = kinv[r >> 7];
+  }
+  __syncthreads();
+  const int M = n_tok[b];
+  const char* qrow = qp + ((int64_t)b * kT + min(t, max(M - 1, 0))) * kRowF;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < 12; ++sl) {
+    f16x8 qh[4], ql[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qh[j] = *reinterpret_cast<const f16x8*>(qrow + sl * kSlabF + j * 16);
+      ql[j] = *reinterpret_cast<const f16x8*>(qrow + sl * kSlabF + 64 + j * 16);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = acc[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 kh = *reinterpret_cast<const f16x8*>(krow[c] + sl * kSlabF + j * 16);
+        const f16x8 kl = *reinterpret_cast<const f16x8*>(krow[c] + sl * kSlabF + 64 + j * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a = __builtin_fmaf((float)kh[e], (float)ql[j][e], a);
+          a = __builtin_fmaf((float)kl[e], (float)qh[j][e], a);
+          a = __builtin_fmaf((float)kh[e], (float)qh[j][e], a);
+        }
+      }
+      acc[c] = a;
+    }
+  }
+  const float cq = qinv[2 * b + (t >> 7)], ct = t < M ? ctok[(int64_t)bl * kT + t] : -INFINITY, rgt = rg[(int64_t)bl * kT + t];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float cfl = ((cq * kscale[c]) * kInvSqrtD) * kLog2e;
+    float e = t < M ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[c], cfl, ct)) * rgt : 0.f;
+    e = sdg_wave_sum(e);
+    if (sdg_lane() == 0) red[c][sdg_wave()] = e;
+  }
+  __syncthreads();
+  if (t < 8 && c0 + t < cmax)
+    cscore[(int64_t)bl * cmax + c0 + t] = t < nc ? (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]) : -INFINITY;
+}
+
+// result: top-k of the exact candidate scores mapped back to ray indices; status[b] = candidates examined, or -1 when the
+// select path cannot answer for this image (bounds unusable, more than cmax candidates, fewer than k) -- the caller falls back.
+__global__ void __launch_bounds__(1024) k_sel_emit(const int64_t* __restrict__ lidx, const float* __restrict__ lval, const int64_t* __restrict__ cand,
+                                                   const int* __restrict__ total, const float* __restrict__ info, const int64_t* __restrict__ idxU,
+                                                   const float* __restrict__ valU, int cmax, int topk, int k_eff, int64_t* __restrict__ idx,
+                                                   float* __restrict__ val, int* __restrict__ status) {
+  const int bl = blockIdx.x, j = threadIdx.x;
+  const float flag = info[bl * 4 + 1];
+  const int n = total[bl];
+  int st = n;
+  if (flag == 1.f) st = 0;
+  else if (flag != 0.f || n > cmax || n < k_eff) st = -1;
+  if (j == 0) status[bl] = st;
+  if (j >= topk) return;
+  if (flag == 1.f) {                       // no tokens: every score is exactly 0 and the k lowest indices win
+    idx[(int64_t)bl * topk + j] = idxU[(int64_t)bl * topk + j];
+    val[(int64_t)bl * topk + j] = j < k_eff ? 0.f : NAN;
+  } else if (st < 0 || j >= k_eff) {
+    idx[(int64_t)bl * topk + j] = -1;
+    val[(int64_t)bl * topk + j] = NAN;
+  } else {
+    idx[(int64_t)bl * topk + j] = cand[(int64_t)bl * cmax + lidx[(int64_t)bl * topk + j]];
+    val[(int64_t)bl * topk + j] = lval[(int64_t)bl * topk + j];
+  }
+}
+
 struct TopkPlan {
   int nb;          // gather blocks per image
   int64_t span;    // indices per gather block
@@ -1421,10 +1714,10 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
           V.tiles_per_group = (int)sdg_cdiv(n_tiles_x, n_groups_x);
           V.n_tiles = n_tiles_x;
           V.n_groups = n_groups_used;
-          auto kern = logits24 ? k_logits_f16x<0, true> : k_logits_f16x<0, false>;
+          auto kern = logits24 ? k_logits_f16x<0, kOutL24> : k_logits_f16x<0, kOutF32>;
 #ifdef SIXDGS_ABLATION   // timing experiments only (tools/ablate_logits.py builds a private copy of the library with it)
           if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
-#define SDG_ABL_CASE(n) case n: kern = logits24 ? k_logits_f16x<n, true> : k_logits_f16x<n, false>; break;
+#define SDG_ABL_CASE(n) case n: kern = logits24 ? k_logits_f16x<n, kOutL24> : k_logits_f16x<n, kOutF32>; break;
             switch (atoi(ab)) {
               SDG_ABL_CASE(1) SDG_ABL_CASE(8) SDG_ABL_CASE(9) SDG_ABL_CASE(2) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59)
               SDG_ABL_CASE(64) SDG_ABL_CASE(2048)
@@ -1563,6 +1856,168 @@ int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops
   if (bytes_total) *bytes_total = by;
   if (launches) *launches = n;
   return rc;
+}
+
+}  // extern "C"
+
+namespace {
+// ---- select path, host side ------------------------------------------------------------------------------------------------
+struct SelectPlan {
+  int64_t stride;      // floats per image row of U / ub (whole 256-ray tiles)
+  int nbc;             // candidate-compaction blocks per image
+  int64_t span;
+  size_t o_partial, o_stats_s, o_stats_g, o_ctok, o_rg, o_qpl, o_ub, o_u, o_idxu, o_valu, o_lidx, o_lval, o_info, o_counts, o_offs,
+      o_total, o_cand, o_cscore, per_image, topk_bytes;
+};
+SelectPlan select_plan(int64_t r, int batch, int topk, int cmax) {
+  SelectPlan p;
+  p.stride = sdg_cdiv(r > 0 ? r : 1, 256) * 256;
+  const TopkPlan tp = topk_plan(r, batch, topk);
+  p.nbc = tp.nb;
+  p.span = tp.span;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += sdg_align(bytes); return at; };
+  p.o_partial = take((size_t)1024 * kT * 2 * sizeof(float));
+  p.o_stats_s = take((size_t)kT * 2 * sizeof(float));
+  p.o_stats_g = take((size_t)kT * 2 * sizeof(float));
+  p.o_ctok = take((size_t)kT * sizeof(float));
+  p.o_rg = take((size_t)kT * sizeof(float));
+  p.o_qpl = take(sdg_align((size_t)kT * kRowF, 1024) + 256);
+  p.o_ub = take((size_t)4 * p.stride * sizeof(float));
+  p.o_u = take((size_t)p.stride * sizeof(float));
+  p.o_idxu = take((size_t)topk * sizeof(int64_t));
+  p.o_valu = take((size_t)topk * sizeof(float));
+  p.o_lidx = take((size_t)topk * sizeof(int64_t));
+  p.o_lval = take((size_t)topk * sizeof(float));
+  p.o_info = take(16);
+  p.o_counts = take((size_t)p.nbc * sizeof(unsigned));
+  p.o_offs = take((size_t)p.nbc * sizeof(unsigned));
+  p.o_total = take(16);
+  p.o_cand = take((size_t)cmax * sizeof(int64_t));
+  p.o_cscore = take((size_t)cmax * sizeof(float));
+  p.per_image = o;
+  const size_t t2 = topk_plan(cmax, batch, topk).bytes;
+  p.topk_bytes = tp.bytes > t2 ? tp.bytes : t2;
+  return p;
+}
+
+// run length of the fp16x3 kernel: a multiple of the CU count of equal-length runs, independent of the batch (batch invariance)
+int f16x_groups(int64_t r) {
+  const int n_tiles_x = (int)sdg_cdiv(r > 0 ? r : 1, kBNX);
+  int g = 1024;
+  while (g > 256 && n_tiles_x / g < 16) g -= 256;
+  if (g > n_tiles_x) g = n_tiles_x;
+  return g;
+}
+}  // namespace
+
+extern "C" {
+
+size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates) {
+  if (batch < 1) batch = 1;
+  const SelectPlan p = select_plan(r, batch, topk, max_candidates);
+  return p.topk_bytes + (size_t)batch * p.per_image;
+}
+
+int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
+                        const float* d_key_scale, int64_t r, const void* sample_planes, const float* d_sample_scale, int64_t r_sample,
+                        int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
+                        sixdgs_stream_t stream, sixdgs_profile* prof) {
+  SDG_CHECK_ARG(r >= 1 && r_sample >= 1 && r_sample <= r && batch >= 0 && topk >= 1 && topk <= 1024 && max_candidates >= topk &&
+                max_candidates <= (1 << 20) && (max_candidates % 8) == 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && sample_planes && d_sample_scale && idx && val && d_status && ws);
+  SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0 && ((uintptr_t)sample_planes % 16) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  const int cmax = max_candidates;
+  int64_t bg = batch > 4096 ? 4096 : batch;
+  while (bg >= 1 && sixdgs_score_select_workspace_bytes(r, (int)bg, topk, cmax) > ws_bytes) --bg;
+  if (bg < 1) return SIXDGS_E_WORKSPACE;
+  bg = sdg_cdiv(batch, sdg_cdiv(batch, bg));
+  const SelectPlan p = select_plan(r, (int)bg, topk, cmax);
+  char* topk_ws = (char*)ws;
+  char* img0 = (char*)ws + p.topk_bytes;
+  // arrays are [bg][...] per field: field f of image bl lives at img0 + f_offset * bg + bl * size_f  (contiguous per field)
+  auto field = [&](size_t off) { return img0 + off * (size_t)bg; };
+  float* partial = (float*)field(p.o_partial);
+  float* stats_s = (float*)field(p.o_stats_s);
+  float* stats_g = (float*)field(p.o_stats_g);
+  float* ctok = (float*)field(p.o_ctok);
+  float* rg = (float*)field(p.o_rg);
+  char* qplanes = field(p.o_qpl);
+  float* ub = (float*)field(p.o_ub);
+  float* U = (float*)field(p.o_u);
+  int64_t* idxU = (int64_t*)field(p.o_idxu);
+  float* valU = (float*)field(p.o_valu);
+  int64_t* lidx = (int64_t*)field(p.o_lidx);
+  float* lval = (float*)field(p.o_lval);
+  float* info = (float*)field(p.o_info);
+  unsigned* counts = (unsigned*)field(p.o_counts);
+  unsigned* offs = (unsigned*)field(p.o_offs);
+  int* total = (int*)field(p.o_total);
+  int64_t* cand = (int64_t*)field(p.o_cand);
+  float* cscore = (float*)field(p.o_cscore);
+  const size_t qpl_img = sdg_align((size_t)kT * kRowF, 1024);
+  const float log2_frac = log2f((float)((double)r / (double)r_sample));
+  const int k_eff = (int)(r < topk ? r : topk);
+  for (int b0 = 0; b0 < batch; b0 += (int)bg) {
+    const int nb = (int)((batch - b0) < bg ? (batch - b0) : bg);
+    // q planes of the group (one power-of-two scale per 128-token half); the per-image planes are packed [nb][256 rows]
+    float* qinv = (float*)(qplanes + (size_t)bg * qpl_img);
+    hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q + (int64_t)b0 * kT * SIXDGS_D, (int64_t)nb * kT,
+                       (int64_t)SIXDGS_D, qplanes, qinv);
+    LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)sample_planes, qinv - 2 * b0, d_sample_scale, nullptr,
+                       partial, r_sample, p.stride, 0, 0, 0, b0, nb, nullptr, nullptr, 0};
+    // (1) pre-pass over the ray sample: reference maxima and sampled denominators
+    {
+      const int g = f16x_groups(r_sample);
+      V.n_tiles = (int)sdg_cdiv(r_sample, kBNX);
+      V.n_groups = g;
+      V.tiles_per_group = (int)sdg_cdiv(V.n_tiles, g);
+      hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(g * nb)), dim3(512), 0, s, V);
+      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(4 * kT), 0, s, partial, g, stats_s);
+      hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)nb), dim3(kT), 0, s, stats_s, d_n_tok, b0, log2_frac, ctok);
+    }
+    // (2) main sweep: U partials per ray, exact denominators per token
+    {
+      const int g = f16x_groups(r);
+      V.kp = (const char*)key_planes;
+      V.kinv = d_key_scale;
+      V.r = r;
+      V.n_tiles = (int)sdg_cdiv(r, kBNX);
+      V.n_groups = g;
+      V.tiles_per_group = (int)sdg_cdiv(V.n_tiles, g);
+      V.ctok = ctok - (int64_t)b0 * kT;
+      V.ub = ub;
+      V.ub_stride = p.stride;
+      double tok = 0.0;
+      for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
+      {
+        // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
+        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + nb * 16.0));
+        hipLaunchKernelGGL((k_logits_f16x<0, kOutUB>), dim3((unsigned)(g * nb)), dim3(512), 0, s, V);
+      }
+      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(4 * kT), 0, s, partial, g, stats_g);
+      hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)nb), dim3(256), 0, s, ub, p.stride, d_n_tok, b0, r, U);
+    }
+    // (3) k-th largest upper bound, candidate threshold, ordered candidate list
+    int st = run_topk(U, p.stride, r, nb, topk, idxU, valU, topk_ws, s);
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)nb), dim3(kT), 0, s, stats_g, d_n_tok, b0, valU, topk, k_eff, info, rg);
+    const dim3 cg((unsigned)p.nbc, (unsigned)nb);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, U, p.stride, r, info, p.span, counts, offs, cand, cmax);
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)nb), dim3(1024), 0, s, counts, p.nbc, offs, total);
+    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, U, p.stride, r, info, p.span, counts, offs, cand, cmax);
+    // (4) exact scores of the candidates, their top-k, ray indices
+    hipLaunchKernelGGL(k_sel_rescore, dim3((unsigned)(cmax / 8), (unsigned)nb), dim3(kT), 0, s, qplanes - (int64_t)b0 * kT * kRowF, qinv - 2 * b0,
+                       (const char*)key_planes, d_key_scale, d_n_tok, b0, ctok, rg, cand, total, cmax, 0, cscore);
+    st = run_topk(cscore, cmax, cmax, nb, topk, lidx, lval, topk_ws, s);
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_emit, dim3((unsigned)nb), dim3(1024), 0, s, lidx, lval, cand, total, info, idxU, valU, cmax, topk, k_eff,
+                       idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0);
+    SDG_LAUNCH_OK();
+  }
+  return 0;
 }
 
 }  // extern "C"

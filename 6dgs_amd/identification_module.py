@@ -131,7 +131,14 @@ class IdentificationModule(torch.nn.Module):
             else:
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
                 planes = None
-            self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale}, ident
+            sample = None
+            if planes_mode and mode in ops.F16_MODES and r >= ops.SELECT_MIN_RAYS:
+                # the ray sample of the select path (ops.score_select): one ray in 16 through the same ray MLP (+6 % set-up work,
+                # +96 B per ray); its planes carry their own tile scales
+                si = ops.select_sample_indices(r, rays_ori.device)
+                _, _, (s_planes, s_scale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
+                sample = (s_planes, s_scale)
+            self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale, "sample": sample}, ident
             self._key_cache_rays = (rays_ori, rays_dir, rays_rgb)
         return self._key_cache
 
@@ -158,7 +165,7 @@ class IdentificationModule(torch.nn.Module):
     def invalidate_caches(self):
         """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
-        self._packed = self._key_cache = self._key_cache_rays = None
+        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = None
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
@@ -200,6 +207,30 @@ class IdentificationModule(torch.nn.Module):
             tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
             n_host = [int(t.shape[0]) for t in token_list]
         q = ops.q_proj(tokens, n_tok, w)
+        self.last_scoring_path = "two-pass"
+        if (not want_scores and kc.get("sample") is not None and ops.select_enabled() and ops.effective_mma_mode() in ops.F16_MODES
+                and rays_to_output <= ops.SELECT_MAX_CANDIDATES and not torch.cuda.is_current_stream_capturing()):
+            # inference: only the top-k is wanted -> no logits through HBM (sixdgs_score_select); images the bounds cannot decide
+            # (status -1: too many near-ties for max_candidates, or an exponent overflow) go through the two-pass scorer below
+            b, r = q.shape[0], rays_ori.shape[0]
+            need = ops.score_select_workspace_bytes(r, b, rays_to_output, ops.SELECT_MAX_CANDIDATES)
+            sw = getattr(self, "_select_ws", None)
+            if sw is None or sw.numel() < need or sw.device != q.device:
+                self._select_ws = sw = None
+                self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
+            idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
+                                                max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host)
+            st = status.tolist()                       # the one host sync of the path (B ints)
+            self.last_select_candidates = st
+            redo = [i for i, v in enumerate(st) if v < 0]
+            self.last_scoring_path = "select" if not redo else f"select+two-pass({len(redo)})"
+            if redo:
+                sel = torch.tensor(redo, device=q.device)
+                i2, v2, _, _ = ops.score_topk(q[sel].contiguous(), n_tok[sel].contiguous(), kc["key"], rays_to_output, want_scores=False,
+                                              workspace=workspace, images_in_flight=images_in_flight, key_planes=kc["planes"],
+                                              key_scale=kc["scale"])
+                idx[sel], val[sel] = i2, v2
+            return idx, val, None
         idx, val, scores, _ = ops.score_topk(q, n_tok, kc["key"], rays_to_output, want_scores=want_scores, workspace=workspace,
                                              images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
                                              key_planes=kc["planes"], key_scale=kc["scale"])

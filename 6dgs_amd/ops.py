@@ -417,6 +417,57 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
     return idx, val, scores, stats
 
 
+SELECT_MAX_CANDIDATES = 4096     # candidates re-scored exactly per image; an image with more falls back to the two-pass scorer
+SELECT_SAMPLE_STRIDE = 16        # the pre-pass sees one ray in 16
+SELECT_MIN_RAYS = 1 << 20        # below this the two-pass scorer is as fast (its logits fit in cache-sized workspaces)
+_select_enabled = True
+
+
+def set_select_enabled(on: bool):
+    """Whether top-k-only requests on fp16 key planes may take sixdgs_score_select (no logits through HBM)."""
+    global _select_enabled
+    _select_enabled = bool(on)
+
+
+def select_enabled() -> bool:
+    return _select_enabled
+
+
+def select_sample_indices(r: int, device, stride: int = SELECT_SAMPLE_STRIDE) -> torch.Tensor:
+    """One ray of every `stride` consecutive ones, at a position that varies pseudo-randomly from group to group (a fixed
+    position would pick the same iso-cell direction of every ellipsoid): indices stride*i + (2654435761 i mod 2^32 >> 13) mod stride."""
+    n = r // stride
+    i = torch.arange(n, dtype=torch.int64, device=device)
+    return i * stride + (((i * 2654435761) & 0xFFFFFFFF) >> 13) % stride
+
+
+def score_select_workspace_bytes(r: int, batch: int, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES) -> int:
+    return int(_lib.load().sixdgs_score_select_workspace_bytes(int(r), int(batch), int(topk), int(max_candidates)))
+
+
+def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
+                 sample_scale: torch.Tensor, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
+                 workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, n_tok_host=None):
+    """Top-k without materialised logits (include/sixdgs.h: sixdgs_score_select).  Returns (idx [B,k], val [B,k], status [B] int32 on
+    the device: candidates examined, or -1 = this image needs the two-pass scorer)."""
+    q = _f32(q)
+    _need_gpu(q, n_tok, key_planes, key_scale, sample_planes, sample_scale)
+    if key_planes.shape[1] != 1536 or sample_planes.shape[1] != 1536:
+        raise RuntimeError("6dgs_amd: score_select needs scaled fp16 key planes (MMA_F16X3)")
+    lib = _lib.load()
+    b, dev, r, rs = q.shape[0], q.device, key_planes.shape[0], sample_planes.shape[0]
+    idx = torch.empty(b, topk, dtype=torch.int64, device=dev)
+    val = torch.empty(b, topk, device=dev)
+    status = torch.empty(b, dtype=torch.int32, device=dev)
+    if workspace is None:
+        workspace = torch.empty(score_select_workspace_bytes(r, b, topk, max_candidates), dtype=torch.uint8, device=dev)
+    h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if (profile is not None and n_tok_host is not None) else None
+    check(lib.sixdgs_score_select(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), r, _p(sample_planes), _p(sample_scale), rs,
+                                  int(topk), int(max_candidates), _p(idx), _p(val), _p(status), _p(workspace), workspace.numel(), _stream(),
+                                  profile.ref if profile is not None else None), "score_select")
+    return idx, val, status
+
+
 def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], workspace: torch.Tensor, topk: int = 100,
                 key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None,
                 profile: Optional["KernelProfile"] = None, n_tok_host=None) -> torch.Tensor:

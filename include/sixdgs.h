@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 2   /* 2: plane-format scorer entry points (key_planes + d_key_scale), pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 3   /* 3: sixdgs_score_select (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -261,6 +261,26 @@ int sixdgs_score_pass1(const float* q, const int32_t* d_n_tok, const int32_t* h_
                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
 int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch, int used_planes, int64_t r, int topk,
                        float* scores, int64_t* idx, float* val, void* ws, size_t ws_bytes, sixdgs_stream_t stream, int mma_mode);
+/* Top-k WITHOUT materialising the logits -- the inference path, where only idx/val are wanted (the reference driver reads nothing
+ * else: test.py:105-107).  Needs the scaled fp16 key planes of ALL r rays (sixdgs_ray_keys_ex, SIXDGS_MMA_F16X3) and those of a
+ * ray SAMPLE (any r_sample <= r rays of the same scene, e.g. one ray in 16, through the same entry point).  score[r] =
+ * sum_t e[t][r] / Z_t with e = exp(logit - ref_t), Z_t = sum_r e[t][r]:
+ *   pre-pass    over the sample: ref_t = sample maximum, Z~_t = sample sum (so that f Z~_t ~ Z_t, f = r / r_sample);
+ *   main sweep  over all rays, one matrix-core pass, nothing of size T x R leaves the chip: U[r] = sum_t e[t][r] / (f Z~_t)
+ *               (4 x 4 B per ray and image instead of 784 B of logits) and the EXACT g_t = Z_t / (f Z~_t);
+ *   bounds      score[r] = sum_t e'[t][r] / g_t lies in [U[r] / g_max, U[r] / g_min], so every ray of the true top-k has
+ *               U[r] >= U_(k) g_min / g_max (U_(k) = k-th largest U);
+ *   re-score    those candidates exactly (fp32, from their key planes and the exact g_t); their top-k (value descending, ties ->
+ *               lowest index) is the result.  The sample decides only how many candidates there are, never the answer.
+ * d_status[b] (device) = number of candidates examined, or -1 when this image must be scored by sixdgs_score_topk_ex instead
+ * (more than max_candidates candidates, or an exponent overflow because a logit exceeds the sample maximum by > 88).
+ * max_candidates: multiple of 8, >= topk.  Workspace ~ 20 B per ray and image. */
+size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);
+int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy for the FLOP count, may be NULL*/,
+                        int batch, const void* key_planes, const float* d_key_scale, int64_t r, const void* sample_planes,
+                        const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,
+                        float* val /*[B,topk]*/, int32_t* d_status /*[B]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
+                        sixdgs_profile* prof);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

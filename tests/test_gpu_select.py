@@ -1,0 +1,144 @@
+"""The select path (sixdgs_score_select: top-k without the [T, R] logits ever reaching HBM) against the two-pass scorer and
+the CPU oracle: same 100 rays in the same order wherever the gaps are real, values within fp32 rounding; plus the cases the
+bounds cannot decide (too many near-ties for max_candidates, exponent overflow), which must be reported (status -1) and fall
+back to the two-pass scorer inside IdentificationModule.score_tokens."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    o = importlib.import_module("6dgs_amd.ops")
+    o.set_mma_mode(o.MMA_DEFAULT)
+    return o
+
+
+def make_case(ops, r, seed, q_scale, n_tok, key_spread=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    key = torch.randn(r, 384, generator=g) * 0.07
+    if key_spread != 1.0:                       # groups of 128 rays with very different magnitudes: exercises the per-tile scales
+        key = key * torch.exp(torch.randn(r // 128 + 1, 1, generator=g) * key_spread).repeat_interleave(128, 0)[:r]
+    q = torch.randn(len(n_tok), 256, 384, generator=g) * q_scale
+    nt = torch.tensor(n_tok, dtype=torch.int32)
+    for b, t in enumerate(n_tok):
+        q[b, t:] = 0.0
+    key, q, nt = key.cuda(), q.cuda(), nt.cuda()
+    planes, scale = ops.split_planes_f16(key)
+    si = ops.select_sample_indices(r, "cuda")
+    s_planes, s_scale = ops.split_planes_f16(key[si].contiguous())
+    return dict(key=key, q=q, nt=nt, planes=planes, scale=scale, s_planes=s_planes, s_scale=s_scale, n_tok=list(n_tok))
+
+
+def check_against_two_pass_and_oracle(ops, oracle, c, k=100, cmax=4096, oracle_images=(0,), allow_giveup=False):
+    idx, val, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], k, max_candidates=cmax)
+    i2, v2, sc, _ = ops.score_topk(c["q"], c["nt"], None, k, key_planes=c["planes"], key_scale=c["scale"], want_scores=True)
+    st = status.tolist()
+    for b, t in enumerate(c["n_tok"]):
+        if st[b] < 0 and allow_giveup:
+            assert int(idx[b].max()) == -1        # no partial answers
+            continue
+        assert st[b] >= 0, f"image {b}: select path gave up ({st[b]})"
+        if t == 0:
+            assert torch.equal(idx[b], i2[b]) and float(val[b].abs().max()) == 0.0
+            continue
+        smax = float(v2[b][0])
+        assert set(idx[b].tolist()) <= set(torch.nonzero(sc[b] >= v2[b][-1] * (1 - 4e-6)).flatten().tolist())   # nothing clearly outside
+        assert float((val[b] - sc[b][idx[b]]).abs().max()) / smax < 2e-6                                        # exact scores of those rays
+        gaps = (v2[b][:-1] - v2[b][1:]) / smax
+        if float(gaps.min()) > 4e-6:            # all gaps real: the same rays in the same order
+            assert torch.equal(idx[b], i2[b])
+        assert bool((val[b][:-1] >= val[b][1:]).all()) and len(set(idx[b].tolist())) == k
+    key_np = c["key"].cpu().numpy()
+    for b in oracle_images:
+        t = c["n_tok"][b]
+        if st[b] < 0:
+            continue
+        s_ref = oracle.attention_scores(c["q"][b, :t].cpu().numpy(), key_np)
+        order = np.argsort(-s_ref, kind="stable")
+        margin = 8e-6 * float(s_ref.max())
+        got = idx[b].cpu().numpy()
+        must = order[:k][s_ref[order[:k]] - s_ref[order[k]] > margin]
+        assert set(must.tolist()) <= set(got.tolist())
+        assert float(s_ref[got].min()) >= float(s_ref[order[k - 1]]) - margin
+        assert np.abs(val[b].cpu().numpy() - s_ref[got]).max() / float(s_ref.max()) < 1e-5
+    return st
+
+
+@pytest.mark.parametrize("q_scale,name", [(0.02, "flat"), (6.0, "moderate"), (45.0, "peaked"), (130.0, "very peaked")])
+def test_select_matches_two_pass_and_oracle(ops, oracle, q_scale, name):
+    """Four softmax regimes (logit spread over the rays = 0.07 q_scale: 0.0014 / 0.42 / 3.2 / 9.1), ragged token counts, R not a
+    multiple of 256.  In the last one a handful of rays carry each token's whole softmax mass, the 1/16 sample misses most of
+    them and the bounds may span more than max_candidates rays: giving up (status -1) is allowed there, a wrong answer is not."""
+    c = make_case(ops, 1_200_037, 11, q_scale, (256, 137, 1, 200))
+    st = check_against_two_pass_and_oracle(ops, oracle, c, oracle_images=(0, 1), allow_giveup=name == "very peaked")
+    print(f"[select {name}] candidates per image: {st}")
+    assert max(st) <= 4096
+
+
+def test_select_zero_token_image_and_tile_scales(ops, oracle):
+    c = make_case(ops, 1_100_000, 5, 1.0, (256, 0, 64), key_spread=3.0)
+    check_against_two_pass_and_oracle(ops, oracle, c, oracle_images=(0, 2))
+
+
+def test_select_reports_what_it_cannot_decide(ops):
+    """(a) a nearly flat softmax with room for 104 candidates only: more rays than that are within the bound's reach -> status -1;
+    (b) a ray outside the sample whose logits exceed the sample maximum by far more than 88: e' overflows -> status -1."""
+    c = make_case(ops, 1_200_000, 3, 0.002, (256, 256))
+    _, _, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=104)
+    assert status.tolist() == [-1, -1]
+    c = make_case(ops, 1_200_000, 4, 1.0, (256,))
+    si = set(ops.select_sample_indices(1_200_000, "cpu").tolist())
+    hot = next(i for i in range(500_000, 500_100) if i not in si)
+    key = c["key"].clone()
+    key[hot] = c["q"][0, 0] * 4000.0 / float(c["q"][0, 0].norm())        # logit of token 0 ~ 4000 * |q| / sqrt(384) >> 88
+    planes, scale = ops.split_planes_f16(key)
+    _, _, status = ops.score_select(c["q"], c["nt"], planes, scale, c["s_planes"], c["s_scale"], 100)
+    assert status.tolist() == [-1]
+    i2, v2, _, _ = ops.score_topk(c["q"], c["nt"], None, 100, key_planes=planes, key_scale=scale)
+    assert int(i2[0, 0]) == hot                      # the two-pass scorer (online maximum) handles it
+
+
+def test_module_takes_the_select_path_and_falls_back(ops, syn, oracle):
+    """IdentificationModule.score_tokens(want_scores=False) on a scene above SELECT_MIN_RAYS: select path, same answer as with
+    want_scores=True (two-pass); with max_candidates forced tiny every image falls back and the answer is still the same."""
+    pkg = importlib.import_module("6dgs_amd")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, strict=False)
+    idm = idm.cuda().eval()
+    rays = syn.make_rays(1_300_000, 2)
+    o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+    toks = [torch.from_numpy(syn.make_tokens(t, 30 + i, 40.0)).cuda() for i, t in enumerate((256, 173, 256))]
+    i_s, v_s, none = idm.score_tokens(toks, o, d, c, 100, want_scores=False)
+    assert none is None and idm.last_scoring_path == "select" and min(idm.last_select_candidates) >= 100
+    i_t, v_t, sc = idm.score_tokens(toks, o, d, c, 100, want_scores=True)
+    assert idm.last_scoring_path == "two-pass"
+    for b in range(3):
+        assert set(i_s[b].tolist()) == set(i_t[b].tolist())
+        assert float((v_s[b] - sc[b][i_s[b]]).abs().max() / v_t[b][0]) < 2e-6
+    flat = [t * 0.0005 for t in toks]           # nearly flat softmax: far more than 104 rays within the bound's reach
+    i_ft, v_ft, sc_f = idm.score_tokens(flat, o, d, c, 100, want_scores=True)
+    old = ops.SELECT_MAX_CANDIDATES
+    try:
+        ops.SELECT_MAX_CANDIDATES = 104
+        i_f, v_f, _ = idm.score_tokens(flat, o, d, c, 100, want_scores=False)
+        assert idm.last_scoring_path == "select+two-pass(3)" and idm.last_select_candidates == [-1, -1, -1]
+    finally:
+        ops.SELECT_MAX_CANDIDATES = old
+    assert torch.equal(i_f, i_ft) and torch.equal(v_f, v_ft)       # the fallback IS the two-pass scorer
+    ops.set_select_enabled(False)
+    try:
+        i_n, v_n, _ = idm.score_tokens(toks, o, d, c, 100, want_scores=False)
+        assert idm.last_scoring_path == "two-pass" and torch.equal(i_n, i_t) and torch.equal(v_n, v_t)
+    finally:
+        ops.set_select_enabled(True)
