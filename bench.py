@@ -82,6 +82,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole per-batch path (image prep, ViT, CNN, scorer, pose solve) in one hipGraph and replay it "
                          "per step: for the launch-bound small-scene regime (--mode reference); kernel timing needs the eager path")
+    ap.add_argument("--no-select", action="store_true",
+                    help="score with the two-pass scorer (logits through HBM) instead of the select path (top-k without materialised logits)")
     ap.add_argument("--l32-steps", type=int, default=-1,
                     help="steps of the secondary fp32-logits measurement (-1 = min(steps, 3) when the main mode is f16x3; 0 = skip)")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
@@ -119,6 +121,7 @@ def main():
     ops = importlib.import_module("6dgs_amd.ops")
     tp = importlib.import_module("6dgs_amd.test")
     ops.set_mma_mode({"default": ops.MMA_DEFAULT, "bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f16x3l32": ops.MMA_F16X3_L32, "f32": ops.MMA_F32}[args.mma])
+    ops.set_select_enabled(not args.no_select)
 
     # test hooks (tests/ and CI only): run the N > 1 code path with several ranks on one device over gloo
     forced_dev = os.environ.get("SIXDGS_BENCH_FORCE_DEVICE")
@@ -183,7 +186,18 @@ def main():
             free_b = torch.cuda.mem_get_info(dev)[0]
             while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100, planes=True) > 0.6 * free_b:
                 inflight -= 1
-        ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
+    # the select path (top-k without materialised logits) serves the timed steps when the scene has a ray sample; the two-pass
+    # workspace (784 B per ray and image) is then only needed for its fallback and for the secondary two-pass figures
+    use_select = (not streamed and not args.graph and ops.select_enabled() and idm._key_cache is not None and idm._key_cache.get("sample") is not None)
+
+    def two_pass_ws():
+        nonlocal ws
+        if ws is None:
+            ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
+        return ws
+
+    if not streamed and not use_select:
+        two_pass_ws()
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------
@@ -242,20 +256,32 @@ def main():
         step(None)
     elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
     l_ms, l_fl, l_by, l_n = prof.collect()
+    path = getattr(idm, "last_scoring_path", "two-pass") if not streamed else "streamed two-pass"
+    cand = list(getattr(idm, "last_select_candidates", [])) if use_select else None
 
     mode = ops.effective_mma_mode()
     mma_name = {ops.MMA_F32: "f32", ops.MMA_BF16X6: "bf16x6", ops.MMA_F16X3: "f16x3", ops.MMA_F16X3_L32: "f16x3l32"}
-    # ---- the same workload with fp32 logits between the two scorer passes (keep the cost of not narrowing visible)
-    l32 = None
-    n32 = (min(args.steps, 3) if args.l32_steps < 0 else args.l32_steps) if (mode == ops.MMA_F16X3 and not args.graph) else 0
+    # ---- the same workload through the two-pass scorer: 24-bit fixed-point logits between the passes, and fp32 logits (VERDICT r1:
+    # keep the cost of not narrowing visible).  The select path above stores no logits at all and re-scores its candidates in fp32.
+    l32, l24 = None, None
+    n32 = (min(args.steps, 3) if args.l32_steps < 0 else args.l32_steps) if (mode == ops.MMA_F16X3 and not args.graph and not streamed) else 0
     if n32 > 0:
+        two_pass_ws()
+        ops.set_select_enabled(False)
+        if use_select:
+            step(None)
+            e24, _, _ = timed(n32, None)
+            l24 = {"mma": "f16x3", "value": round(world * args.batch * n32 / e24, 4), "unit": "poses/s", "steps": n32,
+                   "ms_per_step": round(1e3 * e24 / n32, 3),
+                   "note": "two-pass scorer, logits through HBM as 24-bit fixed point (784 B/ray/image): the round-1 headline path"}
         ops.set_mma_mode(ops.MMA_F16X3_L32)          # same key planes (the cache is keyed on the plane format), 1024 instead of
         step(None)                                   # 784 B of logits per ray and image: the library regroups the images in `ws`
         e32, per32, _ = timed(n32, None)
         ops.set_mma_mode(ops.MMA_DEFAULT if args.mma == "default" else ops.MMA_F16X3)
+        ops.set_select_enabled(not args.no_select)
         l32 = {"mma": "f16x3l32", "value": round(world * args.batch * n32 / e32, 4), "unit": "poses/s", "steps": n32,
                "ms_per_step": round(1e3 * e32 / n32, 3),
-               "note": "logits between the scorer passes as fp32 (1024 B/ray/image) instead of 24-bit fixed point (784 B): no intermediate below fp32"}
+               "note": "two-pass scorer, logits between the passes as fp32 (1024 B/ray/image): no intermediate below fp32"}
 
     poses = world * args.batch * args.steps
     value = poses / elapsed
@@ -269,8 +295,9 @@ def main():
                         "note": "rank-0 wall time of each timed step (every step ends with the poses on the host)"},
         "arithmetic": ("fp32 results; q.K^T as 2 power-of-two-scaled fp16 planes x 3 MFMA terms, dense layers as 3 bf16 planes x 6 MFMA "
                        "terms, fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
-                       + ("; logits travel between the two scorer passes as 24-bit fixed point, absolute error <= 2^-20 per logit "
-                          "(fp32_logits_mode = the same run without that narrowing)" if mode == ops.MMA_F16X3 else "")),
+                       + ("; select path: no logits stored, candidates re-scored in fp32 (nothing below fp32 on the path)" if path.startswith("select") else
+                          ("; logits travel between the two scorer passes as 24-bit fixed point, absolute error <= 2^-20 per logit "
+                           "(fp32_logits_mode = the same run without that narrowing)" if mode == ops.MMA_F16X3 else ""))),
         "config": {
             "workload": (f"{args.config}: synthetic {args.gaussians}-Gaussian scene" + (" (through a 3DGS PLY file)" if args.scene == "ply" else "") + ", "
                          + (f"iso-cell emission from every valid Gaussian x {args.rays_per_ellipsoid} rays" if args.mode == "full"
@@ -292,6 +319,11 @@ def main():
         out["config"]["chunk_rays"] = args.chunk_rays
         out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj "
                                          "and the scorer twice (row statistics, then scores + top-k merge); nothing of size R x 384 is resident")
+    out["config"]["scoring_path"] = path
+    if cand is not None:
+        out["config"]["select_candidates_last_batch"] = cand
+    if l24 is not None:
+        out["two_pass_mode"] = l24
     if l32 is not None:
         out["fp32_logits_mode"] = l32
     if rank == 0:
@@ -299,7 +331,7 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight:
+                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight and tj.get("path", "two-pass") == ("select" if path.startswith("select") else "two-pass"):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = ("%s -- builder's separate rocprofv3 --pmc pass over this same command (round %s), NOT measured in this run"
                                       % (tj.get("source", os.path.relpath(args.traffic_json, ROOT)), tj.get("round")))
@@ -311,9 +343,13 @@ def main():
         out["roofline"] = {
             "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
                                        "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
-                       ops.MMA_F16X3: "k_logits_f16x: q.K^T (256 tokens x 256 rays per tile) with fp32 operands scaled by a power of two and split "
-                                      "into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA rings, "
-                                      "online row stats, logits stored once as 24-bit fixed point",
+                       ops.MMA_F16X3: ("k_logits_f16x<UB> (select path): K.Q^T (256 rays x 256 tokens per tile) with fp32 operands scaled by a power of two "
+                                       "and split into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA "
+                                       "rings; epilogue exp2 + token-sum butterfly, 16 B per ray and image leave the chip (no logits)"
+                                       if path.startswith("select") else
+                                       "k_logits_f16x: q.K^T (256 tokens x 256 rays per tile) with fp32 operands scaled by a power of two and split "
+                                       "into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA rings, "
+                                       "online row stats, logits stored once as 24-bit fixed point"),
                        ops.MMA_F16X3_L32: "k_logits_f16x: as f16x3 with the logits stored as fp32",
                        ops.MMA_F32: "k_logits<f32>: q.K^T on v_mfma_f32_32x32x2_f32, online row stats, logits stored once"}[mode],
             "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

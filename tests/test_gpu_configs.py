@@ -121,8 +121,25 @@ def test_headline_500k_x64_scores_and_top100_against_the_oracle(env, oracle):
     toks = [syn.make_tokens(t, 20 + i, 40.0) for i, t in enumerate((256, 173))]
     idx, val, sc = idm.score_tokens([torch.from_numpy(t).cuda() for t in toks], ori, dr, rgb, 100, want_scores=True)
     assert idm._key_cache["key"] is None and idm._key_cache["planes"].shape == (ori.shape[0], 1536)      # plane path, no fp32 keys resident
+    assert idm.last_scoring_path == "two-pass"
+    # the inference path proper (no score vector asked for): the select path -- no logits through HBM, candidates re-scored exactly
+    i_s, v_s, none = idm.score_tokens([torch.from_numpy(t).cuda() for t in toks], ori, dr, rgb, 100, want_scores=False)
+    assert none is None and idm.last_scoring_path == "select", idm.last_scoring_path
+    print(f"[headline] select path: candidates examined per image {idm.last_select_candidates}")
+    for b in range(2):
+        assert set(i_s[b].tolist()) == set(idx[b].tolist())
+        assert float((v_s[b] - sc[b][i_s[b]]).abs().max() / val[b][0]) < 1e-5
     key_np = host_keys(env, ori, dr, rgb)
-    oracle_check(oracle, env, key_np, toks[0], sc[0].cpu().numpy(), idx[0].cpu().numpy(), val[0].cpu().numpy(), "headline 500k x 64")
+    s_ref = oracle_check(oracle, env, key_np, toks[0], sc[0].cpu().numpy(), idx[0].cpu().numpy(), val[0].cpu().numpy(), "headline 500k x 64")
+    # ... and the select path's answer against the same oracle scores
+    got = i_s[0].cpu().numpy()
+    order = np.argsort(-s_ref, kind="stable")
+    margin = MARGIN * float(s_ref.max())
+    must = order[:100][s_ref[order[:100]] - s_ref[order[100]] > margin]
+    assert set(must.tolist()) <= set(got.tolist()) and float(s_ref[got].min()) >= float(s_ref[order[99]]) - margin
+    assert np.abs(v_s[0].cpu().numpy() - s_ref[got]).max() / float(s_ref.max()) < SCORE_TOL
+    print(f"[headline select] {len(set(order[:100].tolist()) & set(got.tolist()))}/100 identical to the oracle's list")
+    del s_ref
     # pose tail at this size: the oracle's pose from the HIP top-100 (the same rays) within north_star's 1e-4
     up = torch.tensor([[0.2, -0.9, 0.3]], device="cuda")
     up = up / up.norm()
@@ -189,6 +206,14 @@ def test_cfg3_1m_x64_eight_images_per_rank_grouped(env, oracle):
         i1, v1, s1 = idm.score_tokens([toks[b]], ori, dr, rgb, 100, want_scores=True, workspace=ws)
         assert torch.equal(i1[0], idx[b]) and torch.equal(v1[0], val[b]) and torch.equal(s1[0], sc[b])
         del s1
+    # the 8 images through the select path in ONE launch (16 B per ray and image instead of 784: no grouping needed)
+    i_s, v_s, _ = idm.score_tokens(toks, ori, dr, rgb, 100, want_scores=False)
+    assert idm.last_scoring_path == "select", idm.last_scoring_path
+    print(f"[cfg-3] select path: candidates examined per image {idm.last_select_candidates}")
+    for b8 in range(8):
+        if n_t[b8] > 1:
+            assert set(i_s[b8].tolist()) == set(idx[b8].tolist()), b8
+            assert float((v_s[b8] - sc[b8][i_s[b8]]).abs().max() / val[b8][0]) < 1e-5
     b = 2                   # 137 tokens: ragged token count + about half the oracle time of a full image
     s_b, i_b, v_b = sc[b].cpu().numpy(), idx[b].cpu().numpy(), val[b].cpu().numpy()
     del sc, ws
