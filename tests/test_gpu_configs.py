@@ -197,6 +197,11 @@ def test_cfg3_1m_x64_eight_images_per_rank_grouped(env, oracle):
     n_t = (256, 256, 137, 256, 200, 256, 1, 256)
     toks = [torch.from_numpy(syn.make_tokens(t, 40 + i, 40.0)).cuda() for i, t in enumerate(n_t)]
     kc = idm._ensure_keys(ori, dr, rgb)
+    # the 8 images through the select path in ONE launch (20 B of workspace per ray and image instead of 784: no grouping needed)
+    i_s, v_s, _ = idm.score_tokens(toks, ori, dr, rgb, 100, want_scores=False)
+    assert idm.last_scoring_path == "select", idm.last_scoring_path
+    print(f"[cfg-3] select path: candidates examined per image {idm.last_select_candidates}")
+    idm._select_ws = None                                                                                            # 10 GB back before the 150 GB below
     ws = torch.empty(ops.score_topk_workspace_bytes(R, 3, 100, planes=True), dtype=torch.uint8, device="cuda")      # 3 of 8 images fit
     idx, val, sc = idm.score_tokens(toks, ori, dr, rgb, 100, want_scores=True, workspace=ws)
     assert idx.shape == (8, 100) and sc.shape == (8, R)
@@ -206,10 +211,6 @@ def test_cfg3_1m_x64_eight_images_per_rank_grouped(env, oracle):
         i1, v1, s1 = idm.score_tokens([toks[b]], ori, dr, rgb, 100, want_scores=True, workspace=ws)
         assert torch.equal(i1[0], idx[b]) and torch.equal(v1[0], val[b]) and torch.equal(s1[0], sc[b])
         del s1
-    # the 8 images through the select path in ONE launch (16 B per ray and image instead of 784: no grouping needed)
-    i_s, v_s, _ = idm.score_tokens(toks, ori, dr, rgb, 100, want_scores=False)
-    assert idm.last_scoring_path == "select", idm.last_scoring_path
-    print(f"[cfg-3] select path: candidates examined per image {idm.last_select_candidates}")
     for b8 in range(8):
         if n_t[b8] > 1:
             assert set(i_s[b8].tolist()) == set(idx[b8].tolist()), b8
