@@ -1323,8 +1323,8 @@ __global__ void __launch_bounds__(kT) k_sel_prepare(const float* __restrict__ st
 }
 
 // U[bl][r] = sum of the token-quarter partials that exist (waves whose 64 tokens are all padding write nothing)
-__global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub, int64_t stride, const int* __restrict__ n_tok, int b0, int64_t R,
-                                                    float* __restrict__ U) {
+__global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub, int64_t stride, int64_t u_stride, const int* __restrict__ n_tok, int b0,
+                                                    int64_t R, float* __restrict__ U) {
   const int bl = blockIdx.y;
   const int nq = (n_tok[b0 + bl] + 63) >> 6;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1334,17 +1334,22 @@ __global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub
     const float4 v = *reinterpret_cast<const float4*>(ub + ((int64_t)bl * 4 + w) * stride + i);
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
-  *reinterpret_cast<float4*>(U + (int64_t)bl * stride + i) = a;     // stride is a multiple of 256: the tail past R is scratch
+  *reinterpret_cast<float4*>(U + (int64_t)bl * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
+}
+
+// gsum[bl][t] += the sweep's per-token sum (stats_g holds (0, sum) pairs from k_merge_stats)
+__global__ void __launch_bounds__(kT) k_sel_accumulate(const float* __restrict__ stats_g, float* __restrict__ gsum) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  gsum[i] += stats_g[i * 2 + 1];
 }
 
 // per image: g_min / g_max over its tokens, the candidate threshold on U and the validity of the bounds.
 // info[bl][4] = {threshold on U, flag, -, -}: flag 0 ok, 1 = no tokens (all scores are exactly 0), 2 = bounds unusable (overflow / NaN)
-__global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ stats_g, const int* __restrict__ n_tok, int b0, const float* __restrict__ valU,
-                                                   int topk, int k_eff, float* __restrict__ info, float* __restrict__ rg) {
+__global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ gsum, const int* __restrict__ n_tok, const float* __restrict__ valU,
+                                                   int topk, int k_eff, float* __restrict__ info) {
   __shared__ float smin[4], smax[4];
-  const int bl = blockIdx.x, t = threadIdx.x, M = n_tok[b0 + bl];
-  const float g = stats_g[((int64_t)bl * kT + t) * 2 + 1];
-  rg[(int64_t)bl * kT + t] = (t < M && g > 0.f) ? 1.f / g : 0.f;
+  const int bl = blockIdx.x, t = threadIdx.x, M = n_tok[bl];
+  const float g = gsum[(int64_t)bl * kT + t];
   float lo = t < M ? g : INFINITY, hi = t < M ? g : -INFINITY;
   bool bad = t < M && !(g > 0.f && g < INFINITY);
 #pragma unroll
@@ -1369,6 +1374,14 @@ __global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ sta
     info[bl * 4 + 0] = thr;
     info[bl * 4 + 1] = flag;
   }
+}
+
+// d_count[bl] = number of candidates (may exceed max_candidates: the re-score stage then refuses), -1 bounds unusable, -2 no tokens
+__global__ void k_sel_count(const int* __restrict__ total, const float* __restrict__ info, int nb, int* __restrict__ d_count) {
+  const int bl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bl >= nb) return;
+  const float flag = info[bl * 4 + 1];
+  d_count[bl] = flag == 1.f ? -2 : (flag != 0.f ? -1 : total[bl]);
 }
 
 // ordered compaction of {r : U[r] >= threshold}: COUNT -> counts[bl][blk]; WRITE -> cand[bl][pos] = r in ascending r for pos < cmax
@@ -1425,13 +1438,13 @@ __global__ void __launch_bounds__(1024) k_sel_scan(const unsigned* __restrict__ 
 // (scaled fp16 planes, three cross terms) accumulated with fp32 FMAs.
 __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp, const float* __restrict__ qinv, const char* __restrict__ kp,
                                                     const float* __restrict__ kinv, const int* __restrict__ n_tok, int b0,
-                                                    const float* __restrict__ ctok, const float* __restrict__ rg, const int64_t* __restrict__ cand,
+                                                    const float* __restrict__ ctok, const float* __restrict__ gsum, const int64_t* __restrict__ cand,
                                                     const int* __restrict__ total, int cmax, int compact, float* __restrict__ cscore) {
   __shared__ __attribute__((aligned(16))) char krow[8][kRowF];
   __shared__ float kscale[8];
   __shared__ float red[8][4];
   const int bl = blockIdx.y, b = b0 + bl, t = threadIdx.x;
-  const int n = min(total[bl], cmax);
+  const int n = total[bl] > cmax ? 0 : max(total[bl], 0);      // refused images (flags, overflow of the candidate list) cost nothing
   const int c0 = blockIdx.x * 8;
   if (c0 >= n) {
     if (t < 8 && c0 + t < cmax) cscore[(int64_t)bl * cmax + c0 + t] = -INFINITY;
@@ -1473,7 +1486,8 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
       acc[c] = a;
     }
   }
-  const float cq = qinv[2 * b + (t >> 7)], ct = t < M ? ctok[(int64_t)bl * kT + t] : -INFINITY, rgt = rg[(int64_t)bl * kT + t];
+  const float cq = qinv[2 * b + (t >> 7)], ct = t < M ? ctok[(int64_t)bl * kT + t] : -INFINITY;
+  const float gt = gsum[(int64_t)bl * kT + t], rgt = (t < M && gt > 0.f) ? 1.f / gt : 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const float cfl = ((cq * kscale[c]) * kInvSqrtD) * kLog2e;
@@ -1489,19 +1503,17 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
 // result: top-k of the exact candidate scores mapped back to ray indices; status[b] = candidates examined, or -1 when the
 // select path cannot answer for this image (bounds unusable, more than cmax candidates, fewer than k) -- the caller falls back.
 __global__ void __launch_bounds__(1024) k_sel_emit(const int64_t* __restrict__ lidx, const float* __restrict__ lval, const int64_t* __restrict__ cand,
-                                                   const int* __restrict__ total, const float* __restrict__ info, const int64_t* __restrict__ idxU,
-                                                   const float* __restrict__ valU, int cmax, int topk, int k_eff, int64_t* __restrict__ idx,
+                                                   const int* __restrict__ count, int cmax, int topk, int k_eff, int64_t* __restrict__ idx,
                                                    float* __restrict__ val, int* __restrict__ status) {
   const int bl = blockIdx.x, j = threadIdx.x;
-  const float flag = info[bl * 4 + 1];
-  const int n = total[bl];
+  const int n = count[bl];
   int st = n;
-  if (flag == 1.f) st = 0;
-  else if (flag != 0.f || n > cmax || n < k_eff) st = -1;
+  if (n == -2) st = 0;
+  else if (n < 0 || n > cmax || n < k_eff) st = -1;
   if (j == 0) status[bl] = st;
   if (j >= topk) return;
-  if (flag == 1.f) {                       // no tokens: every score is exactly 0 and the k lowest indices win
-    idx[(int64_t)bl * topk + j] = idxU[(int64_t)bl * topk + j];
+  if (n == -2) {                           // no tokens: every score is exactly 0 and the k lowest indices win
+    idx[(int64_t)bl * topk + j] = j < k_eff ? j : -1;
     val[(int64_t)bl * topk + j] = j < k_eff ? 0.f : NAN;
   } else if (st < 0 || j >= k_eff) {
     idx[(int64_t)bl * topk + j] = -1;
@@ -1862,14 +1874,16 @@ int sixdgs_profile_collect(sixdgs_profile* prof, double* ms_total, double* flops
 
 namespace {
 // ---- select path, host side ------------------------------------------------------------------------------------------------
+// Four stages, each an entry point of its own so that the main sweep can run chunk by chunk over a scene whose key planes do not
+// fit the GPU (begin once, sweep per chunk, candidates once, re-score on the keys of the candidates alone); sixdgs_score_select
+// chains them for the resident case.  Every stage takes all `nb` images at once; its scratch comes from one workspace.
 struct SelectPlan {
-  int64_t stride;      // floats per image row of U / ub (whole 256-ray tiles)
+  int64_t stride;      // floats per image row of the ub partials (whole 256-ray tiles)
   int nbc;             // candidate-compaction blocks per image
   int64_t span;
-  size_t o_partial, o_stats_s, o_stats_g, o_ctok, o_rg, o_qpl, o_ub, o_u, o_idxu, o_valu, o_lidx, o_lval, o_info, o_counts, o_offs,
-      o_total, o_cand, o_cscore, per_image, topk_bytes;
+  size_t o_partial, o_stats, o_qpl, o_ub, o_idxu, o_valu, o_lidx, o_lval, o_info, o_counts, o_offs, o_total, o_cscore, per_image, topk_bytes;
 };
-SelectPlan select_plan(int64_t r, int batch, int topk, int cmax) {
+SelectPlan select_plan(int64_t r, int batch, int topk, int cmax, bool with_ub = true) {
   SelectPlan p;
   p.stride = sdg_cdiv(r > 0 ? r : 1, 256) * 256;
   const TopkPlan tp = topk_plan(r, batch, topk);
@@ -1878,13 +1892,9 @@ SelectPlan select_plan(int64_t r, int batch, int topk, int cmax) {
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += sdg_align(bytes); return at; };
   p.o_partial = take((size_t)1024 * kT * 2 * sizeof(float));
-  p.o_stats_s = take((size_t)kT * 2 * sizeof(float));
-  p.o_stats_g = take((size_t)kT * 2 * sizeof(float));
-  p.o_ctok = take((size_t)kT * sizeof(float));
-  p.o_rg = take((size_t)kT * sizeof(float));
+  p.o_stats = take((size_t)kT * 2 * sizeof(float));
   p.o_qpl = take(sdg_align((size_t)kT * kRowF, 1024) + 256);
-  p.o_ub = take((size_t)4 * p.stride * sizeof(float));
-  p.o_u = take((size_t)p.stride * sizeof(float));
+  p.o_ub = take(with_ub ? (size_t)4 * p.stride * sizeof(float) : 16);
   p.o_idxu = take((size_t)topk * sizeof(int64_t));
   p.o_valu = take((size_t)topk * sizeof(float));
   p.o_lidx = take((size_t)topk * sizeof(int64_t));
@@ -1893,12 +1903,44 @@ SelectPlan select_plan(int64_t r, int batch, int topk, int cmax) {
   p.o_counts = take((size_t)p.nbc * sizeof(unsigned));
   p.o_offs = take((size_t)p.nbc * sizeof(unsigned));
   p.o_total = take(16);
-  p.o_cand = take((size_t)cmax * sizeof(int64_t));
   p.o_cscore = take((size_t)cmax * sizeof(float));
   p.per_image = o;
   const size_t t2 = topk_plan(cmax, batch, topk).bytes;
   p.topk_bytes = tp.bytes > t2 ? tp.bytes : t2;
   return p;
+}
+struct SelectWs {
+  SelectPlan p;
+  char *topk_ws, *qplanes;
+  float *partial, *stats, *qinv, *ub, *valU, *lval, *info, *cscore;
+  int64_t *idxU, *lidx;
+  unsigned *counts, *offs;
+  int* total;
+  size_t qpl_img;
+};
+// fields are [nb][...]: field f of image bl lives at base + f_offset * nb + bl * size_f (contiguous per field)
+bool select_ws(void* ws, size_t ws_bytes, int64_t r, int nb, int topk, int cmax, SelectWs* w, bool with_ub = true) {
+  w->p = select_plan(r, nb, topk, cmax, with_ub);
+  if (w->p.topk_bytes + (size_t)nb * w->p.per_image > ws_bytes) return false;
+  w->topk_ws = (char*)ws;
+  char* img0 = (char*)ws + w->p.topk_bytes;
+  auto field = [&](size_t off) { return img0 + off * (size_t)nb; };
+  w->partial = (float*)field(w->p.o_partial);
+  w->stats = (float*)field(w->p.o_stats);
+  w->qplanes = field(w->p.o_qpl);
+  w->qpl_img = sdg_align((size_t)kT * kRowF, 1024);
+  w->qinv = (float*)(w->qplanes + (size_t)nb * w->qpl_img);
+  w->ub = (float*)field(w->p.o_ub);
+  w->idxU = (int64_t*)field(w->p.o_idxu);
+  w->valU = (float*)field(w->p.o_valu);
+  w->lidx = (int64_t*)field(w->p.o_lidx);
+  w->lval = (float*)field(w->p.o_lval);
+  w->info = (float*)field(w->p.o_info);
+  w->counts = (unsigned*)field(w->p.o_counts);
+  w->offs = (unsigned*)field(w->p.o_offs);
+  w->total = (int*)field(w->p.o_total);
+  w->cscore = (float*)field(w->p.o_cscore);
+  return true;
 }
 
 // run length of the fp16x3 kernel: a multiple of the CU count of equal-length runs, independent of the batch (batch invariance)
@@ -1909,14 +1951,132 @@ int f16x_groups(int64_t r) {
   if (g > n_tiles_x) g = n_tiles_x;
   return g;
 }
+
+// scaled fp16 planes of q (one power-of-two scale per 128-token half) for images [0, nb)
+void select_q_planes(const float* q, int nb, const SelectWs& w, hipStream_t s) {
+  hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q, (int64_t)nb * kT, (int64_t)SIXDGS_D, w.qplanes, w.qinv);
+}
+LogitsF16Args select_args(const int32_t* d_n_tok, int nb, const SelectWs& w, const void* planes, const float* scale, int64_t r) {
+  LogitsF16Args V = {w.qplanes, d_n_tok, (const char*)planes, w.qinv, scale, nullptr, w.partial, r, w.p.stride, 0, 0, 0, 0, nb, nullptr, nullptr, 0};
+  V.n_tiles = (int)sdg_cdiv(r, kBNX);
+  V.n_groups = f16x_groups(r);
+  V.tiles_per_group = (int)sdg_cdiv(V.n_tiles, V.n_groups);
+  return V;
+}
 }  // namespace
 
 extern "C" {
 
-size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates) {
+size_t sixdgs_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates) {
   if (batch < 1) batch = 1;
   const SelectPlan p = select_plan(r, batch, topk, max_candidates);
   return p.topk_bytes + (size_t)batch * p.per_image;
+}
+
+size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, int max_candidates) {
+  if (batch < 1) batch = 1;
+  const SelectPlan p = select_plan(r, batch, topk, max_candidates, false);
+  return p.topk_bytes + (size_t)batch * p.per_image;
+}
+
+int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+                        int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1 && r_total >= r_sample);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(q && d_n_tok && sample_planes && d_sample_scale && ctok && gsum && ws && ((uintptr_t)sample_planes % 16) == 0 &&
+                ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, r_sample, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
+  select_q_planes(q, batch, w, s);
+  const LogitsF16Args V = select_args(d_n_tok, batch, w, sample_planes, d_sample_scale, r_sample);
+  hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * batch)), dim3(512), 0, s, V);
+  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, w.stats);
+  hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, d_n_tok, 0, log2f((float)((double)r_total / (double)r_sample)), ctok);
+  hipError_t e = hipMemsetAsync(gsum, 0, (size_t)batch * kT * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
+                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
+                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
+  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && ctok && gsum && u && ws && ((uintptr_t)key_planes % 16) == 0 &&
+                ((uintptr_t)q % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, r, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
+  select_q_planes(q, batch, w, s);
+  LogitsF16Args V = select_args(d_n_tok, batch, w, key_planes, d_key_scale, r);
+  V.ctok = ctok;
+  V.ub = w.ub;
+  V.ub_stride = w.p.stride;
+  double tok = 0.0;
+  for (int i = 0; i < batch; ++i) tok += h_n_tok ? (double)h_n_tok[i] : (double)kT;
+  {
+    // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
+    SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + batch * 16.0));
+    hipLaunchKernelGGL((k_logits_f16x<0, kOutUB>), dim3((unsigned)(V.n_groups * batch)), dim3(512), 0, s, V);
+  }
+  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, w.stats);
+  hipLaunchKernelGGL(k_sel_accumulate, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, gsum);
+  hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)batch), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, 0, r, u);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const int32_t* d_n_tok, int batch, const float* gsum, int topk,
+                             int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(u && d_n_tok && gsum && cand && d_count && ws && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, r, batch, topk, max_candidates, &w, false)) return SIXDGS_E_WORKSPACE;
+  const int k_eff = (int)(r < topk ? r : topk);
+  int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
+  if (st) return st;
+  hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, topk, k_eff, w.info);
+  const dim3 cg((unsigned)w.p.nbc, (unsigned)batch);
+  hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
+  hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
+  hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)sdg_cdiv(batch, 64)), dim3(64), 0, s, w.total, w.info, batch, d_count);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
+                          const float* ctok, const float* gsum, const int64_t* cand, const int32_t* d_count, int64_t r, int topk,
+                          int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r >= 1 && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(q && d_n_tok && planes && d_scale && ctok && gsum && cand && d_count && idx && val && d_status && ws &&
+                ((uintptr_t)planes % 16) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  hipStream_t s = sdg_stream(stream);
+  const int cmax = max_candidates;
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, cmax, batch, topk, cmax, &w, false)) return SIXDGS_E_WORKSPACE;
+  const int k_eff = (int)(r < topk ? r : topk);
+  select_q_planes(q, batch, w, s);
+  hipLaunchKernelGGL(k_sel_rescore, dim3((unsigned)(cmax / 8), (unsigned)batch), dim3(kT), 0, s, w.qplanes, w.qinv, (const char*)planes, d_scale,
+                     d_n_tok, 0, ctok, gsum, cand, d_count, cmax, compact, w.cscore);
+  const int st = run_topk(w.cscore, cmax, cmax, batch, topk, w.lidx, w.lval, w.topk_ws, s);
+  if (st) return st;
+  hipLaunchKernelGGL(k_sel_emit, dim3((unsigned)batch), dim3(1024), 0, s, w.lidx, w.lval, cand, d_count, cmax, topk, k_eff, idx, val, d_status);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates) {
+  if (batch < 1) batch = 1;
+  // stage scratch + ctok, gsum [B,256], U [B, stride], cand [B, cmax], count [B]
+  const size_t stride = (size_t)sdg_cdiv(r > 0 ? r : 1, 256) * 256;
+  return sdg_align(sixdgs_select_workspace_bytes(r, batch, topk, max_candidates)) +
+         (size_t)batch * (2 * sdg_align(kT * sizeof(float)) + sdg_align(stride * sizeof(float)) + sdg_align((size_t)max_candidates * sizeof(int64_t)) + 256);
 }
 
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
@@ -1926,96 +2086,33 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
   SDG_CHECK_ARG(r >= 1 && r_sample >= 1 && r_sample <= r && batch >= 0 && topk >= 1 && topk <= 1024 && max_candidates >= topk &&
                 max_candidates <= (1 << 20) && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
-  SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && sample_planes && d_sample_scale && idx && val && d_status && ws);
-  SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0 && ((uintptr_t)sample_planes % 16) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
-  hipStream_t s = sdg_stream(stream);
-  const int cmax = max_candidates;
+  SDG_CHECK_ARG(q && d_n_tok && idx && val && d_status && ws && ((uintptr_t)ws % 256) == 0);
   int64_t bg = batch > 4096 ? 4096 : batch;
-  while (bg >= 1 && sixdgs_score_select_workspace_bytes(r, (int)bg, topk, cmax) > ws_bytes) --bg;
+  while (bg >= 1 && sixdgs_score_select_workspace_bytes(r, (int)bg, topk, max_candidates) > ws_bytes) --bg;
   if (bg < 1) return SIXDGS_E_WORKSPACE;
   bg = sdg_cdiv(batch, sdg_cdiv(batch, bg));
-  const SelectPlan p = select_plan(r, (int)bg, topk, cmax);
-  char* topk_ws = (char*)ws;
-  char* img0 = (char*)ws + p.topk_bytes;
-  // arrays are [bg][...] per field: field f of image bl lives at img0 + f_offset * bg + bl * size_f  (contiguous per field)
-  auto field = [&](size_t off) { return img0 + off * (size_t)bg; };
-  float* partial = (float*)field(p.o_partial);
-  float* stats_s = (float*)field(p.o_stats_s);
-  float* stats_g = (float*)field(p.o_stats_g);
-  float* ctok = (float*)field(p.o_ctok);
-  float* rg = (float*)field(p.o_rg);
-  char* qplanes = field(p.o_qpl);
-  float* ub = (float*)field(p.o_ub);
-  float* U = (float*)field(p.o_u);
-  int64_t* idxU = (int64_t*)field(p.o_idxu);
-  float* valU = (float*)field(p.o_valu);
-  int64_t* lidx = (int64_t*)field(p.o_lidx);
-  float* lval = (float*)field(p.o_lval);
-  float* info = (float*)field(p.o_info);
-  unsigned* counts = (unsigned*)field(p.o_counts);
-  unsigned* offs = (unsigned*)field(p.o_offs);
-  int* total = (int*)field(p.o_total);
-  int64_t* cand = (int64_t*)field(p.o_cand);
-  float* cscore = (float*)field(p.o_cscore);
-  const size_t qpl_img = sdg_align((size_t)kT * kRowF, 1024);
-  const float log2_frac = log2f((float)((double)r / (double)r_sample));
-  const int k_eff = (int)(r < topk ? r : topk);
+  const size_t stride = (size_t)sdg_cdiv(r, 256) * 256;
+  const size_t stage = sdg_align(sixdgs_select_workspace_bytes(r, (int)bg, topk, max_candidates));
+  char* base = (char*)ws + stage;
+  float* ctok = (float*)base;                        base += (size_t)bg * sdg_align(kT * sizeof(float));
+  float* gsum = (float*)base;                        base += (size_t)bg * sdg_align(kT * sizeof(float));
+  float* u = (float*)base;                           base += (size_t)bg * sdg_align(stride * sizeof(float));
+  int64_t* cand = (int64_t*)base;                    base += (size_t)bg * sdg_align((size_t)max_candidates * sizeof(int64_t));
+  int32_t* count = (int32_t*)base;
   for (int b0 = 0; b0 < batch; b0 += (int)bg) {
     const int nb = (int)((batch - b0) < bg ? (batch - b0) : bg);
-    // q planes of the group (one power-of-two scale per 128-token half); the per-image planes are packed [nb][256 rows]
-    float* qinv = (float*)(qplanes + (size_t)bg * qpl_img);
-    hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q + (int64_t)b0 * kT * SIXDGS_D, (int64_t)nb * kT,
-                       (int64_t)SIXDGS_D, qplanes, qinv);
-    LogitsF16Args V = {qplanes - (int64_t)b0 * kT * kRowF, d_n_tok, (const char*)sample_planes, qinv - 2 * b0, d_sample_scale, nullptr,
-                       partial, r_sample, p.stride, 0, 0, 0, b0, nb, nullptr, nullptr, 0};
-    // (1) pre-pass over the ray sample: reference maxima and sampled denominators
-    {
-      const int g = f16x_groups(r_sample);
-      V.n_tiles = (int)sdg_cdiv(r_sample, kBNX);
-      V.n_groups = g;
-      V.tiles_per_group = (int)sdg_cdiv(V.n_tiles, g);
-      hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(g * nb)), dim3(512), 0, s, V);
-      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(4 * kT), 0, s, partial, g, stats_s);
-      hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)nb), dim3(kT), 0, s, stats_s, d_n_tok, b0, log2_frac, ctok);
-    }
-    // (2) main sweep: U partials per ray, exact denominators per token
-    {
-      const int g = f16x_groups(r);
-      V.kp = (const char*)key_planes;
-      V.kinv = d_key_scale;
-      V.r = r;
-      V.n_tiles = (int)sdg_cdiv(r, kBNX);
-      V.n_groups = g;
-      V.tiles_per_group = (int)sdg_cdiv(V.n_tiles, g);
-      V.ctok = ctok - (int64_t)b0 * kT;
-      V.ub = ub;
-      V.ub_stride = p.stride;
-      double tok = 0.0;
-      for (int i = 0; i < nb; ++i) tok += h_n_tok ? (double)h_n_tok[b0 + i] : (double)kT;
-      {
-        // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
-        SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + nb * 16.0));
-        hipLaunchKernelGGL((k_logits_f16x<0, kOutUB>), dim3((unsigned)(g * nb)), dim3(512), 0, s, V);
-      }
-      hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)nb), dim3(4 * kT), 0, s, partial, g, stats_g);
-      hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)nb), dim3(256), 0, s, ub, p.stride, d_n_tok, b0, r, U);
-    }
-    // (3) k-th largest upper bound, candidate threshold, ordered candidate list
-    int st = run_topk(U, p.stride, r, nb, topk, idxU, valU, topk_ws, s);
+    const float* qg = q + (int64_t)b0 * kT * SIXDGS_D;
+    const int32_t* ng = d_n_tok + b0;
+    int st = sixdgs_select_begin(qg, ng, nb, sample_planes, d_sample_scale, r_sample, r, ctok, gsum, ws, stage, stream);
     if (st) return st;
-    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)nb), dim3(kT), 0, s, stats_g, d_n_tok, b0, valU, topk, k_eff, info, rg);
-    const dim3 cg((unsigned)p.nbc, (unsigned)nb);
-    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, U, p.stride, r, info, p.span, counts, offs, cand, cmax);
-    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)nb), dim3(1024), 0, s, counts, p.nbc, offs, total);
-    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, U, p.stride, r, info, p.span, counts, offs, cand, cmax);
-    // (4) exact scores of the candidates, their top-k, ray indices
-    hipLaunchKernelGGL(k_sel_rescore, dim3((unsigned)(cmax / 8), (unsigned)nb), dim3(kT), 0, s, qplanes - (int64_t)b0 * kT * kRowF, qinv - 2 * b0,
-                       (const char*)key_planes, d_key_scale, d_n_tok, b0, ctok, rg, cand, total, cmax, 0, cscore);
-    st = run_topk(cscore, cmax, cmax, nb, topk, lidx, lval, topk_ws, s);
+    st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, ws, stage,
+                             stream, prof);
     if (st) return st;
-    hipLaunchKernelGGL(k_sel_emit, dim3((unsigned)nb), dim3(1024), 0, s, lidx, lval, cand, total, info, idxU, valU, cmax, topk, k_eff,
-                       idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0);
-    SDG_LAUNCH_OK();
+    st = sixdgs_select_candidates(u, (int64_t)stride, r, ng, nb, gsum, topk, max_candidates, cand, count, ws, stage, stream);
+    if (st) return st;
+    st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates,
+                               idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, stream);
+    if (st) return st;
   }
   return 0;
 }

@@ -165,7 +165,7 @@ class IdentificationModule(torch.nn.Module):
     def invalidate_caches(self):
         """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
-        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = None
+        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = None
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
@@ -258,9 +258,49 @@ class IdentificationModule(torch.nn.Module):
             n_host = [int(t.shape[0]) for t in token_list]
         q = ops.q_proj(tokens, n_tok, w)
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
-        chunk = max(128, (min(chunk_rays, max(r, 1)) + 127) // 128 * 128)       # whole fp16 scale tiles
+        chunk = max(256, (min(chunk_rays, max(r, 1)) + 255) // 256 * 256)       # whole 256-ray tiles (and fp16 scale tiles)
         mode = ops.effective_mma_mode()
         f16, planes_mode = mode in ops.F16_MODES, mode != ops.MMA_F32
+        self.last_scoring_path = "streamed two-pass"
+        if (f16 and not return_stats and ops.select_enabled() and r >= ops.SELECT_MIN_RAYS and k <= ops.SELECT_MAX_CANDIDATES
+                and not torch.cuda.is_current_stream_capturing()):
+            # Select path, streamed: ONE sweep of ray MLP + matrix-core pass over the chunks (plus 1/16 for the sample) instead
+            # of two -- U (4 B per ray and image) is all that is kept of a chunk; the candidates' keys are recomputed at the end.
+            cmax = ops.SELECT_MAX_CANDIDATES
+            held = getattr(self, "_stream_sample", None)
+            ident = (r, rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key)
+            if not (held is not None and held[0] == ident and all(h.data_ptr() == t.data_ptr() for h, t in zip(held[1], (rays_ori, rays_dir, rays_rgb)))):
+                self._stream_sample = held = None
+                si = ops.select_sample_indices(r, dev)
+                _, _, (sp, sscale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
+                self._stream_sample = held = (ident, (rays_ori, rays_dir, rays_rgb), sp, sscale)      # once per scene, like the key cache
+            ss = ops.SelectStream(q, n_tok, r, k, cmax, n_host)
+            ss.begin(held[2], held[3])
+            for r0 in range(0, r, chunk):
+                r1 = min(r0 + chunk, r)
+                _, _, (planes, scale) = ops.ray_keys(rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1], w, want_key=False, want_planes=True)
+                ss.sweep(planes, scale, r0, profile)
+                del planes, scale
+            cand, count = ss.candidates()
+            inside = torch.arange(cmax, device=dev)[None, :] < count.clamp(min=0, max=cmax)[:, None]
+            ci = torch.where(inside, cand, torch.zeros_like(cand)).reshape(-1)
+            _, _, (cp, cs) = ops.ray_keys(rays_ori[ci], rays_dir[ci], rays_rgb[ci], w, want_key=False, want_planes=True)
+            idx, val, status = ss.rescore(cp, cs, cand, count, compact=True)
+            st = status.tolist()                         # the one host sync of the path
+            self.last_select_candidates = st
+            redo = [i for i, v in enumerate(st) if v < 0]
+            self.last_scoring_path = "streamed select" if not redo else f"streamed select+two-pass({len(redo)})"
+            if redo:
+                del ss
+                ops.set_select_enabled(False)
+                try:
+                    sub = tokens[redo] if torch.is_tensor(token_list) else [token_list[i] for i in redo]
+                    i2, v2 = self.score_tokens_streamed(sub, rays_ori, rays_dir, rays_rgb, k, chunk_rays, profile, key_cache_bytes)
+                finally:
+                    ops.set_select_enabled(True)
+                sel = torch.tensor(redo, device=dev)
+                idx[sel], val[sel] = i2, v2
+            return idx, val
         ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), dtype=torch.uint8, device=dev)
         if key_cache_bytes is None:
             key_cache_bytes = int(0.7 * torch.cuda.mem_get_info(dev)[0])

@@ -468,6 +468,72 @@ def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor,
     return idx, val, status
 
 
+class SelectStream:
+    """The select path stage by stage (include/sixdgs.h: sixdgs_select_begin / _sweep / _candidates / _rescore) for ray sets that
+    go through in chunks: begin(sample planes) -> sweep(chunk planes, ray offset) per chunk -> candidates() -> rescore(planes of
+    the candidates).  Holds the caller-side buffers: ctok, gsum [B,256], U [B, R rounded up to 256]."""
+
+    def __init__(self, q: torch.Tensor, n_tok: torch.Tensor, r_total: int, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
+                 n_tok_host=None):
+        self.q, self.n_tok = _f32(q), n_tok
+        _need_gpu(self.q, n_tok)
+        self.b, self.dev = self.q.shape[0], self.q.device
+        self.r, self.topk, self.cmax = int(r_total), int(topk), int(max_candidates)
+        self.stride = (self.r + 255) // 256 * 256
+        self.ctok = torch.empty(self.b, MAX_TOKENS, device=self.dev)
+        self.gsum = torch.empty(self.b, MAX_TOKENS, device=self.dev)
+        self.u = torch.empty(self.b, self.stride, device=self.dev)
+        self.ws = torch.empty(1, dtype=torch.uint8, device=self.dev)
+        self.h_n = (C.c_int32 * self.b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
+
+    def _grow(self, need):
+        if self.ws.numel() < need:
+            self.ws = None
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+
+    def begin(self, sample_planes, sample_scale):
+        _need_gpu(self.q, sample_planes, sample_scale)
+        lib = _lib.load()
+        self._grow(lib.sixdgs_select_workspace_bytes(sample_planes.shape[0], self.b, self.topk, self.cmax))
+        check(lib.sixdgs_select_begin(_p(self.q), _p(self.n_tok), self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0], self.r,
+                                      _p(self.ctok), _p(self.gsum), _p(self.ws), self.ws.numel(), _stream()), "select_begin")
+
+    def sweep(self, planes, scale, ray_offset: int, profile: Optional["KernelProfile"] = None):
+        if ray_offset % 256:
+            raise RuntimeError("6dgs_amd: select sweep chunks must start at a multiple of 256 rays")
+        _need_gpu(self.q, planes, scale)
+        lib = _lib.load()
+        rc = planes.shape[0]
+        self._grow(lib.sixdgs_select_workspace_bytes(rc, self.b, self.topk, self.cmax))
+        check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n if profile is not None else None, self.b, _p(planes), _p(scale), rc,
+                                      _p(self.ctok), _p(self.gsum), C.c_void_p(self.u.data_ptr() + 4 * int(ray_offset)), self.stride,
+                                      _p(self.ws), self.ws.numel(), _stream(), profile.ref if profile is not None else None), "select_sweep")
+
+    def candidates(self):
+        """-> (cand [B,cmax] int64 ascending ray indices, count [B] int32 on the device)"""
+        lib = _lib.load()
+        _need_gpu(self.q)
+        self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
+        cand = torch.zeros(self.b, self.cmax, dtype=torch.int64, device=self.dev)
+        count = torch.empty(self.b, dtype=torch.int32, device=self.dev)
+        check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.n_tok), self.b, _p(self.gsum), self.topk, self.cmax,
+                                           _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
+        return cand, count
+
+    def rescore(self, planes, scale, cand, count, compact: bool):
+        """-> (idx [B,k], val [B,k], status [B] int32)"""
+        lib = _lib.load()
+        _need_gpu(self.q, planes, scale, cand, count)
+        idx = torch.empty(self.b, self.topk, dtype=torch.int64, device=self.dev)
+        val = torch.empty(self.b, self.topk, device=self.dev)
+        status = torch.empty(self.b, dtype=torch.int32, device=self.dev)
+        self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
+        check(lib.sixdgs_select_rescore(_p(self.q), _p(self.n_tok), self.b, _p(planes), _p(scale), 1 if compact else 0, _p(self.ctok),
+                                        _p(self.gsum), _p(cand), _p(count), self.r, self.topk, self.cmax, _p(idx), _p(val), _p(status),
+                                        _p(self.ws), self.ws.numel(), _stream()), "select_rescore")
+        return idx, val, status
+
+
 def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], workspace: torch.Tensor, topk: int = 100,
                 key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None,
                 profile: Optional["KernelProfile"] = None, n_tok_host=None) -> torch.Tensor:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 3   /* 3: sixdgs_score_select (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 3   /* 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -276,6 +276,27 @@ int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch
  * (more than max_candidates candidates, or an exponent overflow because a logit exceeds the sample maximum by > 88).
  * max_candidates: multiple of 8, >= topk.  Workspace ~ 20 B per ray and image. */
 size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);
+/* The four stages of the select path as entry points of their own, for scenes whose key planes do not fit the GPU: `begin` once
+ * (sample pre-pass), `sweep` per ray chunk (chunks start at multiples of 256 rays; each writes its columns of U and adds its
+ * share of the exact per-token sums into gsum), `candidates` once over the whole U, then `rescore` on the key planes of the
+ * candidates alone.  All buffers are the caller's: ctok, gsum [B,256] floats; U [B][u_stride] floats (u_stride >= r rounded up
+ * to 256); cand [B][max_candidates] int64 (ascending ray indices); d_count [B] int32 (candidates, may exceed max_candidates;
+ * -1 bounds unusable; -2 image without tokens).  sixdgs_select_workspace_bytes(r, ...) with the largest r of any call.
+ * rescore: `planes` are either the scene's key planes (compact == 0: rows addressed by ray index, scales per 128 rays) or the
+ * planes of exactly the candidates in candidate order (compact != 0: row b * max_candidates + c, scales per 128 ROWS), e.g.
+ * from sixdgs_ray_keys_ex on the gathered rays. */
+size_t sixdgs_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);              /* begin, sweep: r = rays of the call */
+size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);   /* candidates (r = all rays), rescore */
+int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+                        int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
+                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
+                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const int32_t* d_n_tok, int batch, const float* gsum, int topk,
+                             int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
+                          const float* ctok, const float* gsum, const int64_t* cand, const int32_t* d_count, int64_t r, int topk,
+                          int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy for the FLOP count, may be NULL*/,
                         int batch, const void* key_planes, const float* d_key_scale, int64_t r, const void* sample_planes,
                         const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,

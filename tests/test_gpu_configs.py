@@ -270,3 +270,16 @@ def test_cfg4_2m_x256_rank_share_and_whole_scene_streamed(env, oracle):
         ref = (np.exp(logit - st[:, :1]) / st[:, 1:2]).sum(axis=0)
         assert np.abs(val[b].cpu().numpy() - ref).max() / ref.max() < 1e-5
     print(f"[cfg-4 whole scene] R={R} rays x 16 images streamed in {dt:.1f} s ({16 / dt:.2f} poses/s on one GPU)")
+    del glob, mass
+    # (c) the same through the streamed SELECT path: one sweep (+ the 1/16 sample) instead of two, U = 4 B per ray and image
+    idm._stream_sample = None
+    t0 = time.time()
+    i_s, v_s = idm.score_tokens_streamed(toks, ori, dr, rgb, 100, chunk_rays=8_388_608)
+    torch.cuda.synchronize()
+    dt_s = time.time() - t0
+    assert idm.last_scoring_path == "streamed select", idm.last_scoring_path
+    for b in range(16):
+        if n_t[b] > 1:
+            assert set(i_s[b].tolist()) == set(idx[b].tolist()), b
+            assert float((v_s[b] - val[b]).abs().max() / val[b][0]) < 1e-5
+    print(f"[cfg-4 whole scene, select] {dt_s:.1f} s incl. the sample's keys ({16 / dt_s:.2f} poses/s); candidates {idm.last_select_candidates}")

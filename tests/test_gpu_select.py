@@ -153,3 +153,30 @@ def test_module_takes_the_select_path_and_falls_back(ops, syn, oracle):
         assert idm.last_scoring_path == "two-pass" and torch.equal(i_n, i_t) and torch.equal(v_n, v_t)
     finally:
         ops.set_select_enabled(True)
+
+
+def test_select_stage_by_stage_over_chunks_matches_the_resident_call(ops):
+    """sixdgs_select_begin / _sweep (3 ragged chunks) / _candidates / _rescore on COMPACT planes of the candidates alone -- what the
+    streamed scorer runs for scenes whose key planes exceed the GPU -- against the one-call resident path."""
+    c = make_case(ops, 1_200_037, 21, 6.0, (256, 137, 200))
+    idx, val, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100)
+    assert min(status.tolist()) >= 100
+    ss = ops.SelectStream(c["q"], c["nt"], 1_200_037, 100, 4096, c["n_tok"])
+    ss.begin(c["s_planes"], c["s_scale"])
+    for r0, r1 in ((0, 500_224), (500_224, 900_096), (900_096, 1_200_037)):
+        planes, scale = ops.split_planes_f16(c["key"][r0:r1].contiguous())
+        ss.sweep(planes, scale, r0)
+    cand, count = ss.candidates()
+    assert count.tolist() == status.tolist()                       # the same candidate sets (U is the same bits, g to rounding)
+    inside = torch.arange(4096, device="cuda")[None] < count[:, None]
+    ci = torch.where(inside, cand, torch.zeros_like(cand)).reshape(-1)
+    cp, cs = ops.split_planes_f16(c["key"][ci].contiguous())
+    i2, v2, st2 = ss.rescore(cp, cs, cand, count, compact=True)
+    assert st2.tolist() == status.tolist()
+    for b in range(3):
+        assert set(i2[b].tolist()) == set(idx[b].tolist())
+        assert float((v2[b] - val[b]).abs().max() / val[b][0]) < 2e-6
+    # and on the scene's own planes (compact = False) the staged path is the resident call
+    i3, v3, st3 = ss.rescore(c["planes"], c["scale"], cand, count, compact=False)
+    for b in range(3):
+        assert torch.equal(i3[b], idx[b]) and float((v3[b] - val[b]).abs().max() / val[b][0]) < 1e-6
