@@ -145,6 +145,21 @@ def make_cameras(b: int, seed: int = 0, width: int = 800, height: int = 800, fov
     return cams
 
 
+def make_masked_cameras(seed: int = 9, size: int = 120):
+    """RGBA query views whose alpha channel has STRUCTURE (a disc, a half plane with a soft edge, a small off-centre box), so
+    that the mask -> token selection of the backbone wrapper (backbone.py:86-114) keeps a proper subset of the 256 tokens."""
+    cams = make_cameras(3, seed, width=size, height=size, rgba=True)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    c = (size - 1) / 2.0
+    disc = ((yy - c) ** 2 + (xx - c) ** 2) <= (0.33 * size) ** 2
+    ramp = np.clip((xx - 0.45 * size) / (0.2 * size), 0.0, 1.0)
+    box = (yy > 0.1 * size) & (yy < 0.45 * size) & (xx > 0.55 * size) & (xx < 0.95 * size)
+    for cam, a in zip(cams, (disc * 255.0, ramp * 255.0, box * 200.0)):
+        cam["image"] = cam["image"].copy()
+        cam["image"][..., 3] = a.astype(np.uint8)
+    return cams
+
+
 def checksum(sd: Dict[str, np.ndarray]) -> int:
     """Exact (integer, order-independent) checksum of a dict of fp32 arrays -- guards the fixtures against a
     drift of numpy's RNG streams.  Pure integer arithmetic, so it is identical on every host."""

@@ -595,13 +595,31 @@ def g10(m):
     save("g10_train_step", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g11: a23 BackboneWrapper.forward with structured alpha masks (mask -> token selection, backbone.py:86-114)
+# --------------------------------------------------------------------------------------
+def g11(m):
+    idm = _load_scorer(m, syn.make_scorer_state_dict(0, with_cnn=True))
+    out = {}
+    for i, cam in enumerate(syn.make_masked_cameras(9, 120)):
+        # test.py:69-83 literally
+        obs = torch.from_numpy(np.array(cam["image"])).to(dtype=torch.float32) / 255.0
+        mask = obs[..., -1] > 0.3
+        obs = torch.multiply(obs[..., :3], obs[..., -1:]) + (1 - obs[..., -1:])
+        with torch.no_grad():
+            f_pe, f_flat, fmap = idm.backbone_wrapper(obs, mask)
+        out[f"m{i}_tokens"], out[f"m{i}_flat"], out[f"m{i}_fmap"] = N(f_pe), N(f_flat), N(fmap).astype(np.float32)
+        print(f"  masked camera {i}: {f_pe.shape[0]} of 256 tokens kept")
+    save("g11_backbone_masks", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:
