@@ -1461,7 +1461,9 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
   __syncthreads();
   const int M = n_tok[b];
   const char* qrow = qp + ((int64_t)b * kT + min(t, max(M - 1, 0))) * kRowF;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // fp64 accumulation: every fp16 x fp16 product is exact and 1152 of them sum without rounding that matters, so a candidate's
+  // logit is the exactly rounded contraction of the plane values (the vector fp64 rate makes these 8 x 1152 FMAs per thread free)
+  double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
   for (int sl = 0; sl < 12; ++sl) {
     f16x8 qh[4], ql[4];
 #pragma unroll
@@ -1471,16 +1473,17 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float a = acc[c];
+      double a = acc[c];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f16x8 kh = *reinterpret_cast<const f16x8*>(krow[c] + sl * kSlabF + j * 16);
         const f16x8 kl = *reinterpret_cast<const f16x8*>(krow[c] + sl * kSlabF + 64 + j * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          a = __builtin_fmaf((float)kh[e], (float)ql[j][e], a);
-          a = __builtin_fmaf((float)kl[e], (float)qh[j][e], a);
-          a = __builtin_fmaf((float)kh[e], (float)qh[j][e], a);
+          const double h = (double)(float)kh[e], l = (double)(float)kl[e], qhh = (double)(float)qh[j][e], qll = (double)(float)ql[j][e];
+          a = __builtin_fma(h, qll, a);
+          a = __builtin_fma(l, qhh, a);
+          a = __builtin_fma(h, qhh, a);
         }
       }
       acc[c] = a;
@@ -1491,7 +1494,7 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const float cfl = ((cq * kscale[c]) * kInvSqrtD) * kLog2e;
-    float e = t < M ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[c], cfl, ct)) * rgt : 0.f;
+    float e = t < M ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)acc[c], cfl, ct)) * rgt : 0.f;
     e = sdg_wave_sum(e);
     if (sdg_lane() == 0) red[c][sdg_wave()] = e;
   }

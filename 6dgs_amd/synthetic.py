@@ -160,6 +160,101 @@ def make_masked_cameras(seed: int = 9, size: int = 120):
     return cams
 
 
+def write_dataset_fixtures(root: str, seed: int = 0, n_views: int = 10, width: int = 20, height: int = 14):
+    """Tiny on-disk scenes in the four layouts the reference's loaders read (scene/dataset_loader.py): COLMAP binary and text models
+    (Mip-NeRF360 layout), NSVF / Tanks&Temples, Blender -- plus an experiment directory (`<prefix>_<id>/point_cloud/iteration_N/
+    point_cloud.ply` + `cfg_args`) for each.  Deterministic (numpy RNG + PIL PNG encoder).  Returns {name: source_path}."""
+    import json
+    import os
+    import struct
+    from PIL import Image
+
+    rng = np.random.default_rng(7000 + seed)
+    out = {}
+
+    def poses(n):
+        ps = []
+        for _ in range(n):
+            c2w = np.eye(4)
+            c2w[:3, :3] = random_rotation(rng)
+            c2w[:3, 3] = rng.standard_normal(3) * 2.0
+            ps.append(c2w)
+        return ps
+
+    def quat(rot):       # rotation matrix -> COLMAP (w, x, y, z), w >= 0
+        w = math.sqrt(max(0.0, 1.0 + rot[0, 0] + rot[1, 1] + rot[2, 2])) / 2.0
+        x = math.copysign(math.sqrt(max(0.0, 1.0 + rot[0, 0] - rot[1, 1] - rot[2, 2])) / 2.0, rot[2, 1] - rot[1, 2])
+        y = math.copysign(math.sqrt(max(0.0, 1.0 - rot[0, 0] + rot[1, 1] - rot[2, 2])) / 2.0, rot[0, 2] - rot[2, 0])
+        z = math.copysign(math.sqrt(max(0.0, 1.0 - rot[0, 0] - rot[1, 1] + rot[2, 2])) / 2.0, rot[1, 0] - rot[0, 1])
+        return np.array([w, x, y, z])
+
+    # ---- COLMAP, binary + text (two cameras: PINHOLE and SIMPLE_PINHOLE in the binary model; PINHOLE only in the text model)
+    for kind in ("colmap_bin", "colmap_txt"):
+        src = os.path.join(root, kind)
+        os.makedirs(os.path.join(src, "sparse", "0"), exist_ok=True)
+        os.makedirs(os.path.join(src, "images"), exist_ok=True)
+        open(os.path.join(src, "sparse", "0", "points3D.ply"), "wb").close()       # present (unreadable): the loaders do not regenerate it
+        cams = [(1, 1, width, height, [17.5, 16.25, width / 2.0, height / 2.0])]
+        if kind == "colmap_bin":
+            cams.append((2, 0, width, height, [19.0, width / 2.0, height / 2.0]))
+        names = [f"img_{(i * 7) % n_views:03d}.png" for i in range(n_views)]           # file order != name order
+        recs = []
+        for i, (nm, c2w) in enumerate(zip(names, poses(n_views))):
+            w2c = np.linalg.inv(c2w)
+            recs.append((i + 1, quat(w2c[:3, :3]), w2c[:3, 3], cams[i % len(cams)][0], nm))
+            Image.fromarray(rng.integers(0, 256, size=(height, width, 3), dtype=np.uint8), "RGB").save(os.path.join(src, "images", nm))
+        if kind == "colmap_bin":
+            with open(os.path.join(src, "sparse", "0", "cameras.bin"), "wb") as f:
+                f.write(struct.pack("<Q", len(cams)))
+                for cid, model, w, h, par in cams:
+                    f.write(struct.pack("<iiQQ", cid, model, w, h) + struct.pack("<" + "d" * len(par), *par))
+            with open(os.path.join(src, "sparse", "0", "images.bin"), "wb") as f:
+                f.write(struct.pack("<Q", len(recs)))
+                for iid, q, t, cid, nm in recs:
+                    f.write(struct.pack("<idddddddi", iid, *q, *t, cid) + nm.encode() + b"\x00")
+                    npts = int(rng.integers(0, 4))
+                    f.write(struct.pack("<Q", npts))
+                    for _ in range(npts):
+                        f.write(struct.pack("<ddq", float(rng.random()), float(rng.random()), -1))
+        else:
+            with open(os.path.join(src, "sparse", "0", "cameras.txt"), "w") as f:
+                f.write("# Camera list with one line of data per camera:\n")
+                for cid, model, w, h, par in cams:
+                    f.write(f"{cid} PINHOLE {w} {h} " + " ".join(repr(float(v)) for v in par) + "\n")
+            with open(os.path.join(src, "sparse", "0", "images.txt"), "w") as f:
+                f.write("# Image list with two lines of data per image:\n")
+                for iid, q, t, cid, nm in recs:
+                    f.write(f"{iid} " + " ".join(repr(float(v)) for v in list(q) + list(t)) + f" {cid} {nm}\n")
+                    f.write("1.0 2.0 -1\n")
+        out[kind] = src
+
+    # ---- NSVF / Tanks&Temples: split 0 = train, 1 = test here (no split 2: the loader falls back to 1), RGBA images
+    src = os.path.join(root, "tt")
+    os.makedirs(os.path.join(src, "pose"), exist_ok=True)
+    os.makedirs(os.path.join(src, "rgb"), exist_ok=True)
+    open(os.path.join(src, "points3d.ply"), "wb").close()
+    np.savetxt(os.path.join(src, "intrinsics.txt"), np.array([[21.0, 0, width / 2.0, 0], [0, 20.5, height / 2.0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+    for i, c2w in enumerate(poses(n_views)):
+        tag = f"{0 if i % 3 else 1}_{i:04d}"
+        np.savetxt(os.path.join(src, "pose", tag + ".txt"), c2w)
+        Image.fromarray(rng.integers(0, 256, size=(height, width, 4), dtype=np.uint8), "RGBA").save(os.path.join(src, "rgb", tag + ".png"))
+    out["tt"] = src
+
+    # ---- Blender
+    src = os.path.join(root, "blender")
+    for split, n in (("train", n_views - 3), ("test", 3)):
+        os.makedirs(os.path.join(src, split), exist_ok=True)
+        frames = []
+        for i, c2w in enumerate(poses(n)):
+            Image.fromarray(rng.integers(0, 256, size=(height, width, 4), dtype=np.uint8), "RGBA").save(os.path.join(src, split, f"r_{i}.png"))
+            frames.append({"file_path": f"./{split}/r_{i}", "transform_matrix": c2w.tolist()})
+        with open(os.path.join(src, f"transforms_{split}.json"), "w") as f:
+            json.dump({"camera_angle_x": 0.69, "frames": frames}, f)
+    open(os.path.join(src, "points3d.ply"), "wb").close()
+    out["blender"] = src
+    return out
+
+
 def checksum(sd: Dict[str, np.ndarray]) -> int:
     """Exact (integer, order-independent) checksum of a dict of fp32 arrays -- guards the fixtures against a
     drift of numpy's RNG streams.  Pure integer arithmetic, so it is identical on every host."""

@@ -613,13 +613,72 @@ def g11(m):
     save("g11_backbone_masks", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g12: dataset camera loaders (scene/dataset_loader.py:5-20 -> colmap.py, tanksandtemples.py, synthetic.py) on the tiny on-disk
+# scenes of synthetic.write_dataset_fixtures, and experiment discovery (pose_estimation/file_utils.py:19-72)
+# --------------------------------------------------------------------------------------
+def g12(m):
+    import tempfile
+    dl = importlib.import_module("scene.dataset_loader")
+    # file_utils imports the ANTLR-generated cfg_grammar (antlr4 is absent here): stub the import, only the discovery functions are used
+    cg = types.ModuleType("cfg_grammar")
+    cg.parse_config = lambda text: (_ for _ in ()).throw(RuntimeError("antlr4 absent"))
+    sys.modules.setdefault("cfg_grammar", cg)
+    fu = importlib.import_module("pose_estimation.file_utils")
+    out = {}
+    # Environment shim: the T&T / Blender readers call Image.fromarray(int8 array, "RGB") (tanksandtemples.py:64, synthetic.py:49).  The
+    # Pillow the reference pins (environment.yml) takes the buffer as raw bytes when a mode is given; the Pillow of this image refuses
+    # int8.  Restore the pinned behaviour: same bytes, viewed as uint8.
+    from PIL import Image as PILImage
+    orig_fromarray = PILImage.fromarray
+
+    def fromarray_compat(obj, mode=None):
+        a = np.asarray(obj)
+        return orig_fromarray(a.view(np.uint8) if (mode is not None and a.dtype == np.int8) else a, mode)
+
+    PILImage.fromarray = fromarray_compat
+    with tempfile.TemporaryDirectory() as td:
+        srcs = syn.write_dataset_fixtures(td, 0)
+        for name, src in srcs.items():
+            for ev, wb in ((True, False), (False, True)):
+                args = fu.dotdict(source_path=src, images=None, eval=ev, white_background=wb)
+                info = dl.load_data(args)
+                tag = f"{name}_e{int(ev)}w{int(wb)}"
+                for split, cams in (("train", info.train_cameras), ("test", info.test_cameras)):
+                    out[f"{tag}_{split}_n"] = np.int64(len(cams))
+                    if not cams:
+                        continue
+                    out[f"{tag}_{split}_RT"] = np.stack([np.concatenate([np.asarray(c.R, np.float64).reshape(9), np.asarray(c.T, np.float64),
+                                                                         [c.FovY, c.FovX, c.width, c.height, c.uid]]) for c in cams])
+                    out[f"{tag}_{split}_names"] = np.array([c.image_name for c in cams])
+                    out[f"{tag}_{split}_img"] = np.stack([np.array(c.image) for c in cams])
+                out[f"{tag}_radius"] = np.float64(info.nerf_normalization["radius"])
+                out[f"{tag}_translate"] = np.asarray(info.nerf_normalization["translate"], np.float64)
+                out[f"{tag}_prefix"] = np.array(dl.get_dataset_prefix(src))
+                print(f"  {tag}: {len(info.train_cameras)} train / {len(info.test_cameras)} test cameras")
+        # experiment discovery
+        exp = os.path.join(td, "output")
+        for d, its in (("mip_360_garden_ab12", (7000, 30000)), ("mip_360_room_cd34", (30000,)), ("tt_Ignatius_ef56", (100, 20)), ("tt_empty_gh78", ()),
+                       ("synthetic_lego_0001", (5,))):
+            os.makedirs(os.path.join(exp, d, "point_cloud"), exist_ok=True)
+            for it in its:
+                os.makedirs(os.path.join(exp, d, "point_cloud", f"iteration_{it}"), exist_ok=True)
+                open(os.path.join(exp, d, "point_cloud", f"iteration_{it}", "point_cloud.ply"), "wb").close()
+        os.makedirs(os.path.join(exp, "tt_Ignatius_ef56", "point_cloud", "iteration_900"), exist_ok=True)      # no ply inside: not valid
+        os.makedirs(os.path.join(exp, "mip_360_room_cd34", "point_cloud", "notes_1"), exist_ok=True)
+        for prefix in ("", "mip_360_", "tt_", "synthetic_"):
+            found = fu.parse_exp_dir(exp, prefix)
+            out[f"exp_{prefix or 'all'}"] = np.array([f"{k}|{v['category_name']}|{os.path.relpath(v['checkpoint_filepath'], exp)}" for k, v in found.items()])
+    save("g12_datasets", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:

@@ -128,7 +128,7 @@ def test_headline_500k_x64_scores_and_top100_against_the_oracle(env, oracle):
     print(f"[headline] select path: candidates examined per image {idm.last_select_candidates}")
     for b in range(2):
         assert set(i_s[b].tolist()) == set(idx[b].tolist())
-        assert float((v_s[b] - sc[b][i_s[b]]).abs().max() / val[b][0]) < 1e-5
+        assert float((v_s[b] - sc[b][i_s[b]]).abs().max() / val[b][0]) < 2e-5
     key_np = host_keys(env, ori, dr, rgb)
     s_ref = oracle_check(oracle, env, key_np, toks[0], sc[0].cpu().numpy(), idx[0].cpu().numpy(), val[0].cpu().numpy(), "headline 500k x 64")
     # ... and the select path's answer against the same oracle scores
@@ -214,7 +214,7 @@ def test_cfg3_1m_x64_eight_images_per_rank_grouped(env, oracle):
     for b8 in range(8):
         if n_t[b8] > 1:
             assert set(i_s[b8].tolist()) == set(idx[b8].tolist()), b8
-            assert float((v_s[b8] - sc[b8][i_s[b8]]).abs().max() / val[b8][0]) < 1e-5
+            assert float((v_s[b8] - sc[b8][i_s[b8]]).abs().max() / val[b8][0]) < 2e-5
     b = 2                   # 137 tokens: ragged token count + about half the oracle time of a full image
     s_b, i_b, v_b = sc[b].cpu().numpy(), idx[b].cpu().numpy(), val[b].cpu().numpy()
     del sc, ws
@@ -281,5 +281,5 @@ def test_cfg4_2m_x256_rank_share_and_whole_scene_streamed(env, oracle):
     for b in range(16):
         if n_t[b] > 1:
             assert set(i_s[b].tolist()) == set(idx[b].tolist()), b
-            assert float((v_s[b] - val[b]).abs().max() / val[b][0]) < 1e-5
+            assert float((v_s[b] - val[b]).abs().max() / val[b][0]) < 2e-5
     print(f"[cfg-4 whole scene, select] {dt_s:.1f} s incl. the sample's keys ({16 / dt_s:.2f} poses/s); candidates {idm.last_select_candidates}")
