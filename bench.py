@@ -184,7 +184,7 @@ def main():
             inflight = min(args.in_flight, args.batch)
         else:
             free_b = torch.cuda.mem_get_info(dev)[0]
-            while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100, planes=True) > 0.6 * free_b:
+            while inflight > 1 and ops.score_topk_workspace_bytes(R, inflight, 100) > 0.6 * free_b:
                 inflight -= 1
     # the select path (top-k without materialised logits) serves the timed steps when the scene has a ray sample; the two-pass
     # workspace (784 B per ray and image) is then only needed for its fallback and for the secondary two-pass figures
@@ -193,7 +193,9 @@ def main():
     def two_pass_ws():
         nonlocal ws
         if ws is None:
-            ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100, planes=True), dtype=torch.uint8, device=dev)
+            # sized for fp32 logits (1024 B per ray and image) so that the fp32-logits figure runs in the same buffer; the 24-bit
+            # mode (784 B) then has room to spare
+            ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100), dtype=torch.uint8, device=dev)
         return ws
 
     if not streamed and not use_select:
