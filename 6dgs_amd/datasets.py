@@ -170,7 +170,10 @@ def nerfpp_norm(cams) -> dict:
         w2c = np.eye(4)
         w2c[:3, :3] = np.asarray(c.R).T
         w2c[:3, 3] = np.asarray(c.T)
-        centres.append(np.linalg.inv(w2c)[:3, 3])
+        # the reference goes world-to-view -> inverse -> inverse again and hands the matrix on as float32 (graphics_utils.py:42-53);
+        # the camera centre is then read from the inverse of that single-precision matrix
+        w2c32 = np.float32(np.linalg.inv(np.linalg.inv(w2c)))
+        centres.append(np.linalg.inv(w2c32)[:3, 3])
     centres = np.stack(centres, axis=1)
     centre = centres.mean(axis=1, keepdims=True)
     radius = float(np.linalg.norm(centres - centre, axis=0).max()) * 1.1

@@ -36,7 +36,7 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tup
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SIXDGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -116,6 +116,35 @@ def gather_poses(c2w: torch.Tensor, status: Optional[torch.Tensor] = None, dst: 
         return None, None
     allp = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     return allp[:, :16].reshape(-1, 4, 4), allp[:, 16].to(torch.int32)
+
+
+def rank() -> int:
+    return dist.get_rank() if is_dist() else 0
+
+
+def world() -> int:
+    return dist.get_world_size() if is_dist() else 1
+
+
+def broadcast_int(value: int, src: int, device) -> int:
+    """One integer from rank `src` to every rank."""
+    if not is_dist():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.broadcast(t, src)
+    return int(t.item())
+
+
+def gather_results(results: list, dst: int = 0) -> list:
+    """Per-rank lists of picklable result records (the dicts of test_pose_estimation) -> on `dst` their concatenation in rank order
+    (ranks hold contiguous blocks of the test views, so this is view order); the other ranks keep their own block."""
+    if not is_dist():
+        return results
+    bufs = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(results, bufs, dst=dst)
+    if dist.get_rank() != dst:
+        return results
+    return [r for block in bufs for r in block]
 
 
 def barrier():

@@ -2,6 +2,7 @@
 IdentificationModule, test_pose_estimation) against the g7 fixtures, which were produced by running
 the reference's own functions on the same synthetic scene / weights / cameras."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -296,3 +297,82 @@ def test_full_pipeline_with_backbone_runs(pkg, e2e):
     dense = amap.materialize()
     assert rel_err(N(dense.sum(0)), N(scores)) < 1e-4
     assert abs(float(up.norm()) - 1) < 1e-5
+
+
+def _write_experiment(root, syn, pkg, name, dataset_src, n_gauss, seed):
+    exp = os.path.join(root, "output", name)
+    scene = pkg.GaussianScene.from_dict(syn.make_scene(n_gauss, seed), device="cuda")
+    scene.save_ply(os.path.join(exp, "point_cloud", "iteration_30000", "point_cloud.ply"))
+    scene.save_ply(os.path.join(exp, "point_cloud", "iteration_7000", "point_cloud.ply"))
+    with open(os.path.join(exp, "cfg_args"), "w") as f:
+        f.write(f"Namespace(sh_degree=3, source_path='{dataset_src}', model_path='{exp}', images='images', resolution=-1, "
+                "white_background=False, data_device='cuda', eval=True)")
+
+
+class _TinyBackbone(torch.nn.Module):
+    """patch-embed stand-in for DINOv2 (weights are not downloadable): deterministic, so every rank builds the same one"""
+
+    def __init__(self):
+        super().__init__()
+        self.proj = torch.nn.Conv2d(3, 384, 14, stride=14, bias=False)
+        with torch.no_grad():
+            self.proj.weight.copy_(torch.from_numpy((np.random.default_rng(77).standard_normal((384, 3, 14, 14)) / 24.2).astype(np.float32)))
+
+    def forward_features(self, x):
+        return {"x_norm_patchtokens": self.proj(x).flatten(2).transpose(1, 2)}
+
+
+def test_evaluation_sweep_over_an_experiment_directory(pkg, syn, tmp_path):
+    """The reference's entry point end to end (pretrain_eval_attention.py:200-248): experiment discovery, cfg_args, PLY, dataset
+    cameras (a COLMAP scene and a Tanks&Temples scene), checkpoint load / short training, rays, both passes of
+    test_pose_estimation, results.json."""
+    import json
+    sweep = importlib.import_module("6dgs_amd.pretrain_eval_attention")
+    root = str(tmp_path)
+    srcs = syn.write_dataset_fixtures(os.path.join(root, "data"), 0, n_views=10, width=64, height=48)
+    _write_experiment(root, syn, pkg, "mip_360_garden_ab12", srcs["colmap_bin"], 3000, 1)
+    _write_experiment(root, syn, pkg, "tt_Ignatius_cd34", srcs["tt"], 2500, 2)
+    os.makedirs(os.path.join(root, "output", "tt_broken_ef56", "point_cloud"))        # no checkpoint: skipped with a message
+    out = os.path.join(root, "results", "pose_eval.json")
+    # scene 1 has a checkpoint (reference layout), scene 2 trains for 2 iterations
+    idm = pkg.IdentificationModule("dino", backbone=_TinyBackbone())
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+    torch.save({"epoch": 1500, "model_state_dict": idm.state_dict()}, os.path.join(root, "output", "mip_360_garden_ab12", "id_module.th"))
+    res = sweep.main(["--exp_path", os.path.join(root, "output"), "--out_path", out, "--data_type", "all", "--n_iterations", "2"], backbone=_TinyBackbone())
+    on_disk = json.load(open(out))
+    assert on_disk == json.loads(json.dumps(res)) and len(res) == 2 + 4           # 10 COLMAP views -> 2 test (llffhold 8); T&T: 4 of split 1
+    assert [r["sequence_id"] for r in res] == ["ab12"] * 2 + ["cd34"] * 4 and res[0]["category_name"] == "mip_360_garden"
+    assert [r["frame_id"] for r in res] == [0, 1, 0, 1, 2, 3]
+    for r in res:
+        assert set(r) == {"sequence_id", "category_name", "frame_id", "loss", "scores_loss", "recall", "total_optimization_time_in_ms", "pred_c2w", "gt_c2w"}
+        assert np.asarray(r["pred_c2w"]).shape == (4, 4) and np.isfinite(np.asarray(r["gt_c2w"])).all()
+    assert os.path.exists(os.path.join(root, "output", "tt_Ignatius_cd34", "id_module.th"))      # trained and saved in the reference layout
+    # --data_type filters by directory prefix; a loaded checkpoint is deterministic: the COLMAP scene scores the same again
+    res2 = sweep.main(["--exp_path", os.path.join(root, "output"), "--out_path", out, "--data_type", "mip360", "--skip_train"], backbone=_TinyBackbone())
+    assert len(res2) == 2 and [r["pred_c2w"] for r in res2] == [r["pred_c2w"] for r in res[:2]]
+
+
+def test_evaluation_sweep_sharded_over_two_ranks_gives_the_same_file(pkg, syn, tmp_path):
+    """The same sweep as one process and as two ranks (test views in contiguous blocks, scene + weights broadcast from rank 0, results
+    gathered in view order): identical results.json.  One GPU here, so the ranks share it over gloo (SIXDGS_DIST_BACKEND /
+    SIXDGS_FORCE_DEVICE test hooks); on a node the same code runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = str(tmp_path)
+    srcs = syn.write_dataset_fixtures(os.path.join(root, "data"), 1, n_views=26, width=64, height=48)
+    _write_experiment(root, syn, pkg, "mip_360_room_aa11", srcs["colmap_txt"], 3000, 4)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SIXDGS_RANDOM_BACKBONE="1", SIXDGS_DIST_BACKEND="gloo", SIXDGS_FORCE_DEVICE="0")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for n, launcher in ((1, []), (2, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547"])):
+        out = os.path.join(root, f"res_{n}.json")
+        p = subprocess.run([sys.executable, "-W", "ignore", *launcher, os.path.join(repo, "pretrain_eval_attention.py"), "--exp_path", os.path.join(root, "output"),
+                            "--out_path", out, "--data_type", "mip360", "--skip_train", "--batch_size", "3"], cwd=repo, env=env, capture_output=True, text=True, timeout=500)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.load(open(out)))
+    assert len(outs[0]) == 4 and [r["frame_id"] for r in outs[1]] == [0, 1, 2, 3]          # 26 views, llffhold 8 -> 4 test views
+    for a, b in zip(*outs):
+        assert a["gt_c2w"] == b["gt_c2w"]
+        assert np.abs(np.asarray(a["pred_c2w"]) - np.asarray(b["pred_c2w"])).max() < 1e-5
