@@ -354,7 +354,8 @@ def test_evaluation_sweep_over_an_experiment_directory(pkg, syn, tmp_path):
 
 def test_evaluation_sweep_sharded_over_two_ranks_gives_the_same_file(pkg, syn, tmp_path):
     """The same sweep as one process and as two ranks (test views in contiguous blocks, scene + weights broadcast from rank 0, results
-    gathered in view order): identical results.json.  One GPU here, so the ranks share it over gloo (SIXDGS_DIST_BACKEND /
+    gathered in view order): identical results.json (rays from EVERY Gaussian, so that no random subsample separates the runs:
+    with the reference's 1000-ellipsoid subsample the multi-rank run draws its permutation from a broadcast seed).  One GPU here, so the ranks share it over gloo (SIXDGS_DIST_BACKEND /
     SIXDGS_FORCE_DEVICE test hooks); on a node the same code runs one rank per GPU over RCCL."""
     import json
     import subprocess
@@ -369,7 +370,7 @@ def test_evaluation_sweep_sharded_over_two_ranks_gives_the_same_file(pkg, syn, t
     for n, launcher in ((1, []), (2, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547"])):
         out = os.path.join(root, f"res_{n}.json")
         p = subprocess.run([sys.executable, "-W", "ignore", *launcher, os.path.join(repo, "pretrain_eval_attention.py"), "--exp_path", os.path.join(root, "output"),
-                            "--out_path", out, "--data_type", "mip360", "--skip_train", "--batch_size", "3"], cwd=repo, env=env, capture_output=True, text=True, timeout=500)
+                            "--out_path", out, "--data_type", "mip360", "--skip_train", "--batch_size", "3", "--max_ellipsoids", "-1"], cwd=repo, env=env, capture_output=True, text=True, timeout=500)
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.load(open(out)))
     assert len(outs[0]) == 4 and [r["frame_id"] for r in outs[1]] == [0, 1, 2, 3]          # 26 views, llffhold 8 -> 4 test views
