@@ -173,6 +173,31 @@ def _center_crop(x, size):
     return x[..., top:top + size, left:left + size]
 
 
+class BatchedTokens:
+    """The [n, T, 384 + 14] token block of n images that keep all T tokens, held as its two parts: patch features [n,T,384] and
+    the grid position encoding [T,14] shared by all images.  Behaves like the dense tensor where the path reads it (shape, len,
+    indexing an image, .dense())."""
+
+    def __init__(self, feats: torch.Tensor, pe: torch.Tensor):
+        self.feats, self.pe = feats, pe
+        self.shape = torch.Size((feats.shape[0], feats.shape[1], feats.shape[2] + pe.shape[1]))
+        self.device = feats.device
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, int):
+            return torch.cat([self.feats[i], self.pe], dim=-1)
+        return BatchedTokens(self.feats[i], self.pe)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def dense(self) -> torch.Tensor:
+        return torch.cat([self.feats, self.pe[None].expand(self.shape[0], -1, -1)], dim=-1)
+
+
 class BackboneWrapper(torch.nn.Module):
     def __init__(self, backbone_type: str = "dino", backbone: Optional[torch.nn.Module] = None) -> None:
         super().__init__()
@@ -231,10 +256,12 @@ class BackboneWrapper(torch.nn.Module):
         return with_pe[mask_img].view(-1, with_pe.shape[-1]), feat_hw[mask_img].view(-1, feat_hw.shape[-1]), feat_hw.permute(2, 0, 1)
 
     def assemble_batch(self, feats):
-        """[n,16,16,384] (all tokens valid) -> (tokens+pe [n,256,398], fmaps [n,384,16,16])"""
+        """[n,16,16,384] (all tokens valid) -> (tokens+pe as BatchedTokens [n,256,398], fmaps [n,384,16,16]).  The 14 position
+        channels are the same for every image, so the concatenation (backbone.py:110-114) is not materialised: the scorer's
+        q_proj takes the patch features and adds the position part of the projection as a per-token bias."""
         pe = self.position_encoding(feats.dtype, feats.device)
-        with_pe = torch.cat([feats, pe[None].expand(feats.shape[0], -1, -1, -1)], dim=-1)
-        return with_pe.reshape(feats.shape[0], -1, with_pe.shape[-1]), feats.permute(0, 3, 1, 2)
+        n = feats.shape[0]
+        return BatchedTokens(feats.reshape(n, -1, feats.shape[-1]), pe.reshape(-1, pe.shape[-1])), feats.permute(0, 3, 1, 2)
 
     def forward(self, img, mask=None):
         norm_img, mask_img = self.preprocess(img, mask)

@@ -510,38 +510,74 @@ struct IsoArgs {
   int64_t E, K;
   int scale_is_log, sh_degree, n_coef;
 };
-// one workgroup per group of ellipsoids; thread = (ellipsoid, direction).  Per-ellipsoid data
-// (rotation, Rodrigues matrix, SH) is recomputed per thread from L1/L2-resident lines: the kernel is
-// bound by the 36 B/ray it writes.
+// One workgroup per kIsoEPB ellipsoids.  Phase 1: one thread per ellipsoid builds what all of its K rays share -- rotation
+// matrix of the quaternion, Rodrigues matrix of the normal, reciprocal... (the divisions stay per ray, as in the reference
+// order of operations), centre -- and all threads gather the 48 SH coefficients, everything into LDS (the previous version
+// recomputed all of it per ray from L2 and kept the SH block in scratch: 0.48 TB/s).  Phase 2: the block walks the E*K rays
+// of its ellipsoids 256 at a time: per-ray arithmetic from LDS, results staged in LDS, then written as three contiguous
+// runs (ori / dir / rgb: every wave instruction stores 256 consecutive bytes).  The kernel is bound by the 36 B per ray it writes.
+constexpr int kIsoEPB = 16;
 __global__ void __launch_bounds__(256) k_emit_isocell(IsoArgs A) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= A.E * A.K) return;
-  int64_t e = i / A.K, k = i - e * A.K;
-  int64_t g = A.sel ? A.sel[e] : e;
-  float s0 = A.scale[3 * g], s1 = A.scale[3 * g + 1], s2 = A.scale[3 * g + 2];
-  if (A.scale_is_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
-  float q[4] = {A.rot[4 * g], A.rot[4 * g + 1], A.rot[4 * g + 2], A.rot[4 * g + 3]};
-  float R[9], Rm[9];
-  quat_to_rotmat(q, R);
-  isocell_rotation(v3(A.normals[3 * e], A.normals[3 * e + 1], A.normals[3 * e + 2]), Rm);
-  V3 d = isocell_apply(Rm, v3(A.dirs[3 * k], A.dirs[3 * k + 1], A.dirs[3 * k + 2]));
-  // surface point of the ellipsoid along d: local dl = R^T d, t = 1/sqrt(sum (dl_i/s_i)^2)
-  float l0 = (R[0] * d.x + R[3] * d.y) + R[6] * d.z;
-  float l1 = (R[1] * d.x + R[4] * d.y) + R[7] * d.z;
-  float l2 = (R[2] * d.x + R[5] * d.y) + R[8] * d.z;
-  float u0 = l0 / s0, u1 = l1 / s1, u2 = l2 / s2;
-  float t = 1.f / sqrtf((u0 * u0 + u1 * u1) + u2 * u2);
-  A.ori[3 * i] = A.xyz[3 * g] + t * d.x;
-  A.ori[3 * i + 1] = A.xyz[3 * g + 1] + t * d.y;
-  A.ori[3 * i + 2] = A.xyz[3 * g + 2] + t * d.z;
-  A.dir[3 * i] = d.x; A.dir[3 * i + 1] = d.y; A.dir[3 * i + 2] = d.z;
-  if (A.src) A.src[i] = g;
-  if (A.rgb) {
-    float sh[48];
-    for (int c = 0; c < 3; ++c) sh[c] = A.f_dc[3 * g + c];
-    for (int kk = 1; kk < A.n_coef && kk < 16; ++kk)
-      for (int c = 0; c < 3; ++c) sh[3 * kk + c] = A.f_rest[(g * (A.n_coef - 1) + (kk - 1)) * 3 + c];
-    for (int c = 0; c < 3; ++c) A.rgb[3 * i + c] = sh_channel(sh + c, 3, A.sh_degree, -d.x, -d.y, -d.z);
+  __shared__ float eR[kIsoEPB][9], eRm[kIsoEPB][9], eS[kIsoEPB][3], eC[kIsoEPB][3], eSh[kIsoEPB][48];
+  __shared__ long long eG[kIsoEPB];
+  __shared__ float stage[3][768];
+  const int t = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * kIsoEPB;
+  const int ne = (int)min((int64_t)kIsoEPB, A.E - e0);
+  if (t < ne) {
+    const int64_t e = e0 + t, g = A.sel ? A.sel[e] : e;
+    eG[t] = g;
+    float s0 = A.scale[3 * g], s1 = A.scale[3 * g + 1], s2 = A.scale[3 * g + 2];
+    if (A.scale_is_log) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
+    eS[t][0] = s0; eS[t][1] = s1; eS[t][2] = s2;
+    const float q[4] = {A.rot[4 * g], A.rot[4 * g + 1], A.rot[4 * g + 2], A.rot[4 * g + 3]};
+    float R[9], Rm[9];
+    quat_to_rotmat(q, R);
+    isocell_rotation(v3(A.normals[3 * e], A.normals[3 * e + 1], A.normals[3 * e + 2]), Rm);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { eR[t][c] = R[c]; eRm[t][c] = Rm[c]; }
+    eC[t][0] = A.xyz[3 * g]; eC[t][1] = A.xyz[3 * g + 1]; eC[t][2] = A.xyz[3 * g + 2];
+  }
+  __syncthreads();
+  if (A.rgb)
+    for (int idx = t; idx < ne * 48; idx += 256) {
+      const int el = idx / 48, c = idx - el * 48, kk = c / 3, ch = c - kk * 3;
+      const int64_t g = eG[el];
+      eSh[el][c] = kk == 0 ? A.f_dc[3 * g + ch] : (kk < A.n_coef ? A.f_rest[(g * (A.n_coef - 1) + (kk - 1)) * 3 + ch] : 0.f);
+    }
+  __syncthreads();
+  const int64_t total = (int64_t)ne * A.K, base = e0 * A.K;
+  for (int64_t p = 0; p < total; p += 256) {
+    const int64_t r = p + t;
+    if (r < total) {
+      const int el = (int)(r / A.K);
+      const int64_t k = r - (int64_t)el * A.K;
+      const V3 d = isocell_apply(eRm[el], v3(A.dirs[3 * k], A.dirs[3 * k + 1], A.dirs[3 * k + 2]));
+      // surface point of the ellipsoid along d: local dl = R^T d, t = 1/sqrt(sum (dl_i/s_i)^2)
+      const float* R = eR[el];
+      const float l0 = (R[0] * d.x + R[3] * d.y) + R[6] * d.z;
+      const float l1 = (R[1] * d.x + R[4] * d.y) + R[7] * d.z;
+      const float l2 = (R[2] * d.x + R[5] * d.y) + R[8] * d.z;
+      const float u0 = l0 / eS[el][0], u1 = l1 / eS[el][1], u2 = l2 / eS[el][2];
+      const float tt = 1.f / sqrtf((u0 * u0 + u1 * u1) + u2 * u2);
+      stage[0][3 * t] = eC[el][0] + tt * d.x;
+      stage[0][3 * t + 1] = eC[el][1] + tt * d.y;
+      stage[0][3 * t + 2] = eC[el][2] + tt * d.z;
+      stage[1][3 * t] = d.x; stage[1][3 * t + 1] = d.y; stage[1][3 * t + 2] = d.z;
+      if (A.rgb)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) stage[2][3 * t + c] = sh_channel(eSh[el] + c, 3, A.sh_degree, -d.x, -d.y, -d.z);
+      if (A.src) A.src[base + r] = eG[el];
+    }
+    __syncthreads();
+    const int n3 = 3 * (int)min((int64_t)256, total - p);
+    const int64_t o = 3 * (base + p);
+    for (int idx = t; idx < n3; idx += 256) {
+      A.ori[o + idx] = stage[0][idx];
+      A.dir[o + idx] = stage[1][idx];
+      if (A.rgb) A.rgb[o + idx] = stage[2][idx];
+    }
+    __syncthreads();
   }
 }
 
@@ -748,7 +784,7 @@ int sixdgs_emit_isocell(const float* xyz, const float* scale, int scale_is_log, 
   SDG_CHECK_ARG(xyz && scale && rot && normals && dirs && ori && dir);
   SDG_CHECK_ARG(!rgb || (f_dc && (n_coef == 1 || f_rest)));
   IsoArgs A = {xyz, scale, rot, f_dc, f_rest, normals, dirs, sel, ori, dir, rgb, src, e, k, scale_is_log, sh_degree, n_coef};
-  hipLaunchKernelGGL(k_emit_isocell, grid1d(e * k, 256), dim3(256), 0, sdg_stream(stream), A);
+  hipLaunchKernelGGL(k_emit_isocell, grid1d(e, kIsoEPB), dim3(256), 0, sdg_stream(stream), A);
   SDG_LAUNCH_OK();
   return 0;
 }

@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import ops
-from .backbone import BackboneWrapper
+from .backbone import BackboneWrapper, BatchedTokens
 from .camera_direction_network import CameraDirectionPredictor
 
 
@@ -162,10 +162,38 @@ class IdentificationModule(torch.nn.Module):
             self._ntok_cache = c = torch.full((max(b, 64),), ops.MAX_TOKENS, dtype=torch.int32, device=device)
         return c[:b]
 
+    def _tokens_to_q(self, token_list, device):
+        """The Q side of the boundary: (q [B,256,384], n_tok device int32 [B], n_tok host list, tokens as handed in).
+        list of [T_i,398] -> zero-padded block + sixdgs_q_proj; BatchedTokens (every image keeps all 256 tokens) -> the fused form:
+        q = feats . Wq[:, :384]^T + (pe . Wq[:, 384:]^T + bq), the bracket being one [256,384] table per set of weights -- no
+        [B,256,398] concatenation, no padding copy (SURVEY 8(f)#2: PE concat + q_proj fused)."""
+        w = self.packed_weights(device)
+        if isinstance(token_list, BatchedTokens):
+            b, t = token_list.shape[0], token_list.shape[1]
+            if t != ops.MAX_TOKENS:
+                token_list = token_list.dense()
+            else:
+                wq, bq = self.attention.q_proj.weight, self.attention.q_proj.bias
+                key = (self._packed_key, token_list.pe.data_ptr())
+                if getattr(self, "_peq", None) is None or self._peq[0] != key:
+                    self._peq = (key, torch.addmm(bq.detach(), token_list.pe, wq.detach()[:, ops.D:].t()).contiguous(),
+                                 wq.detach()[:, :ops.D].contiguous())
+                q = ops.linear(token_list.feats.reshape(b * t, ops.D), self._peq[2]).view(b, t, ops.D)
+                q += self._peq[1]
+                return q, self._full_ntok(b, device), [t] * b
+        if torch.is_tensor(token_list):          # pre-batched dense [B,256,398]: every image has all 256 tokens
+            tokens = token_list.contiguous()
+            n_host = [tokens.shape[1]] * tokens.shape[0]
+            n_tok = self._full_ntok(tokens.shape[0], tokens.device)
+        else:
+            tokens, n_tok = ops.pad_tokens(token_list, device)
+            n_host = [int(t.shape[0]) for t in token_list]
+        return ops.q_proj(tokens, n_tok, w), n_tok, n_host
+
     def invalidate_caches(self):
         """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
-        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = None
+        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = self._peq = None
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
@@ -199,14 +227,7 @@ class IdentificationModule(torch.nn.Module):
         """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
         kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
-        if torch.is_tensor(token_list):          # pre-batched [B,256,398]: every image has all 256 tokens
-            tokens = token_list.contiguous()
-            n_host = [tokens.shape[1]] * tokens.shape[0]
-            n_tok = self._full_ntok(tokens.shape[0], tokens.device)
-        else:
-            tokens, n_tok = ops.pad_tokens(token_list, rays_ori.device)
-            n_host = [int(t.shape[0]) for t in token_list]
-        q = ops.q_proj(tokens, n_tok, w)
+        q, n_tok, n_host = self._tokens_to_q(token_list, rays_ori.device)
         self.last_scoring_path = "two-pass"
         if (not want_scores and kc.get("sample") is not None and ops.select_enabled() and ops.effective_mma_mode() in ops.F16_MODES
                 and rays_to_output <= ops.SELECT_MAX_CANDIDATES and not torch.cuda.is_current_stream_capturing()):
@@ -250,13 +271,7 @@ class IdentificationModule(torch.nn.Module):
         [B,256,2], softmax mass per image = sum of all scores, which must equal the image's token count)."""
         dev = rays_ori.device
         w = self.packed_weights(dev)
-        if torch.is_tensor(token_list):
-            tokens, n_tok = token_list.contiguous(), self._full_ntok(token_list.shape[0], dev)
-            n_host = [tokens.shape[1]] * tokens.shape[0]
-        else:
-            tokens, n_tok = ops.pad_tokens(token_list, dev)
-            n_host = [int(t.shape[0]) for t in token_list]
-        q = ops.q_proj(tokens, n_tok, w)
+        q, n_tok, n_host = self._tokens_to_q(token_list, dev)
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
         chunk = max(256, (min(chunk_rays, max(r, 1)) + 255) // 256 * 256)       # whole 256-ray tiles (and fp16 scale tiles)
         mode = ops.effective_mma_mode()
@@ -294,7 +309,7 @@ class IdentificationModule(torch.nn.Module):
                 del ss
                 ops.set_select_enabled(False)
                 try:
-                    sub = tokens[redo] if torch.is_tensor(token_list) else [token_list[i] for i in redo]
+                    sub = token_list[torch.tensor(redo, device=dev)] if (torch.is_tensor(token_list) or isinstance(token_list, BatchedTokens)) else [token_list[i] for i in redo]
                     i2, v2 = self.score_tokens_streamed(sub, rays_ori, rays_dir, rays_rgb, k, chunk_rays, profile, key_cache_bytes)
                 finally:
                     ops.set_select_enabled(True)
@@ -361,7 +376,7 @@ class IdentificationModule(torch.nn.Module):
         up = self.camera_up(fmaps)
         idx, val, scores = self.score_tokens(toks, rays_ori, rays_dir, rays_rgb, rays_to_output, want_scores, workspace,
                                              images_in_flight)
-        tl = list(toks) if torch.is_tensor(toks) else toks
+        tl = list(toks) if (torch.is_tensor(toks) or isinstance(toks, BatchedTokens)) else toks
         return dict(idx=idx, values=val, scores=scores, camera_up_dir=up, n_tokens=[int(t.shape[0]) for t in tl], tokens=tl)
 
     @torch.no_grad()

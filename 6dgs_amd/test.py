@@ -137,7 +137,7 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
         if image_graph and not torch.cuda.is_current_stream_capturing():
             cache = id_module.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
             res = cache.run(id_module, images)
-        if res is not None and torch.is_tensor(res[0]):
+        if res is not None and not isinstance(res[0], (list, tuple)):
             tokens, up = res
         else:
             imgs_f, masks = prepare_images_device(images)

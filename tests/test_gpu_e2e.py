@@ -377,3 +377,26 @@ def test_evaluation_sweep_sharded_over_two_ranks_gives_the_same_file(pkg, syn, t
     for a, b in zip(*outs):
         assert a["gt_c2w"] == b["gt_c2w"]
         assert np.abs(np.asarray(a["pred_c2w"]) - np.asarray(b["pred_c2w"])).max() < 1e-5
+
+
+def test_fused_position_encoding_and_q_proj(pkg, syn):
+    """for images that keep all 256 tokens the [B,256,398] concatenation of patch features and grid position
+    encoding is not built; q = feats . Wq[:, :384]^T + (pe . Wq[:, 384:]^T + bq).  Same q as the reference's Linear(398 -> 384) on
+    the concatenated tokens (our_multihead_attention.py:72) up to the rounding of a re-associated sum."""
+    bb = importlib.import_module("6dgs_amd.backbone")
+    ops = importlib.import_module("6dgs_amd.ops")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, strict=False)
+    idm = idm.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(5, 256, 384, generator=g).cuda() * 2.0
+    pe = idm.backbone_wrapper.position_encoding(torch.float32, feats.device).reshape(256, 14)
+    bt = bb.BatchedTokens(feats, pe)
+    q_fused, n_tok, n_host = idm._tokens_to_q(bt, feats.device)
+    q_dense, _, _ = idm._tokens_to_q(bt.dense(), feats.device)                      # zero-padded block + sixdgs_q_proj
+    q_ref = torch.nn.functional.linear(bt.dense().double().cpu(), idm.attention.q_proj.weight.double().cpu(), idm.attention.q_proj.bias.double().cpu())
+    scale = float(q_ref.abs().max())
+    assert n_host == [256] * 5 and n_tok.tolist() == [256] * 5
+    assert float((q_fused.double().cpu() - q_ref).abs().max()) / scale < 1e-6
+    assert float((q_dense.double().cpu() - q_ref).abs().max()) / scale < 1e-6
+    assert torch.equal(bt[2], bt.dense()[2]) and bt[torch.tensor([1, 3])].shape == (2, 256, 398)
