@@ -78,6 +78,7 @@ class IdentificationModule(torch.nn.Module):
         self.camera_up_out_augmentation = None
         self.camera_direction_prediction_network = CameraDirectionPredictor(nf, self.backbone_wrapper.backbone_wh, fea_output=3)
         self.attention = MultiHeadAttention(nf, nf + 14, nf, 1)
+        self.hip_autograd = True        # training forward/backward of the dense layers on the HIP GEMM when the tensors live on the GPU
         self._packed = None
         self._packed_key = None
         self._key_cache = None
@@ -414,6 +415,9 @@ class IdentificationModule(torch.nn.Module):
         rp = self.ray_preprocessor
         x = torch.cat((rays_ori, rays_dir, rays_rgb, self._pe(rays_ori, rp.pospe), self._pe(rays_dir, rp.viewpe),
                        self._pe(rays_rgb, rp.rgbpe)), dim=-1)
+        if x.is_cuda and self.hip_autograd:          # forward and backward GEMMs on the MFMA kernel (6dgs_amd/autograd.py)
+            from . import autograd as hip
+            return hip.ray_mlp(rp, x)
         return rp.mlp2(torch.cat((rp.mlp(x), x), dim=-1))
 
     def forward(self, img: torch.Tensor, mask: torch.Tensor, rays_ori: torch.Tensor, rays_dir: torch.Tensor, rays_rgb: torch.Tensor,
@@ -428,7 +432,12 @@ class IdentificationModule(torch.nn.Module):
             used = used[:rays_to_test]
         t_pe, t_flat, fmap = self.backbone_wrapper(img, mask)
         feat = self.ray_features_autograd(rays_ori[used], rays_dir[used], rays_rgb[used])
-        q, k = self.attention.q_proj(t_pe), self.attention.k_proj(feat)
+        if feat.is_cuda and self.hip_autograd:
+            from . import autograd as hip
+            q = hip.linear(t_pe, self.attention.q_proj.weight, self.attention.q_proj.bias)
+            k = hip.linear(feat, self.attention.k_proj.weight, self.attention.k_proj.bias)
+        else:
+            q, k = self.attention.q_proj(t_pe), self.attention.k_proj(feat)
         attention_map = torch.softmax((q @ k.transpose(-2, -1)) / (q.shape[-1] ** 0.5), dim=-1)
         scores = attention_map.sum(dim=0)
         up = torch.nn.functional.normalize(self.camera_direction_prediction_network(fmap), dim=-1)

@@ -400,3 +400,43 @@ def test_fused_position_encoding_and_q_proj(pkg, syn):
     assert float((q_fused.double().cpu() - q_ref).abs().max()) / scale < 1e-6
     assert float((q_dense.double().cpu() - q_ref).abs().max()) / scale < 1e-6
     assert torch.equal(bt[2], bt.dense()[2]) and bt[torch.tensor([1, 3])].shape == (2, 256, 398)
+
+
+def test_hip_backward_of_the_dense_layers_matches_pytorch_autograd(pkg, syn):
+    """forward + backward of the ray MLP and q/k_proj on the hand-written MFMA GEMM (6dgs_amd/autograd.py) against
+    PyTorch autograd (rocBLAS) on the same weights and rays: features, keys and every parameter gradient."""
+    ops = importlib.import_module("6dgs_amd.ops")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, strict=False)
+    idm = idm.cuda().train()
+    rays = syn.make_rays(5003, 6)                       # not a multiple of 16: exercises the zero padding of the dW contraction
+    o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+    tok = torch.from_numpy(syn.make_tokens(137, 4, 1.0)).cuda()
+    g = torch.Generator().manual_seed(1)
+    probe_k, probe_q = torch.randn(5003, 384, generator=g).cuda(), torch.randn(137, 384, generator=g).cuda()
+    hip = importlib.import_module("6dgs_amd.autograd")
+
+    def run(use_hip):
+        idm.zero_grad()
+        idm.hip_autograd = use_hip
+        feat = idm.ray_features_autograd(o, d, c)
+        if use_hip:
+            k = hip.linear(feat, idm.attention.k_proj.weight, idm.attention.k_proj.bias)
+            q = hip.linear(tok, idm.attention.q_proj.weight, idm.attention.q_proj.bias)
+        else:
+            k, q = idm.attention.k_proj(feat), idm.attention.q_proj(tok)
+        ((k * probe_k).sum() + (q * probe_q).sum() + feat.square().sum()).backward()
+        grads = {n: p.grad.detach().clone() for n, p in idm.named_parameters() if p.grad is not None}
+        return feat.detach(), k.detach(), q.detach(), grads
+
+    f1, k1, q1, g1 = run(True)
+    f0, k0, q0, g0 = run(False)
+    idm.hip_autograd = True
+    for a, b in ((f1, f0), (k1, k0), (q1, q0)):
+        assert float((a - b).abs().max() / b.abs().max()) < 5e-6
+    assert set(g1) == set(g0) and len(g1) == 12
+    for n in g0:
+        assert float((g1[n] - g0[n]).abs().max() / g0[n].abs().max()) < 2e-5, n
+    # the inference library computes the same features (sixdgs_ray_keys) as the training forward
+    feat_inf = idm.ray_features(o, d, c)
+    assert float((feat_inf - f1).abs().max() / f1.abs().max()) < 5e-6
