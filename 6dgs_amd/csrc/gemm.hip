@@ -13,7 +13,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 template <int MMA, bool RELU>
 __global__ void __launch_bounds__(256, 2) k_linear(GemmOperands g, const float* __restrict__ bias, float* __restrict__ y,
-                                                    int64_t ldy, unsigned n_tiles, unsigned total_tiles) {
+                                                    int64_t ldy, unsigned n_tiles, unsigned total_tiles, float* __restrict__ out_rowmax) {
   __shared__ __attribute__((aligned(16))) char smem[TileSmem<MMA>::kBytes];
   const unsigned w = xcd_remap(blockIdx.x, total_tiles);
   const int64_t row0 = (int64_t)(w / n_tiles) * 128;
@@ -22,22 +22,92 @@ __global__ void __launch_bounds__(256, 2) k_linear(GemmOperands g, const float* 
   gemm_tile<MMA>(g, row0, col0, smem, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  float ib[2] = {1.f, 1.f};
+  if (MMA == kMmaF16x3) {      // undo the per-row operand scales (exact powers of two)
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int64_t col = col0 + acc_col(wn, tn, lane);
-    const float bv = (bias != nullptr && col < g.n) ? bias[col] : 0.f;
+    for (int tn = 0; tn < 2; ++tn) ib[tn] = f3_inv_scale(g.bmax[min(col0 + acc_col(wn, tn, lane), g.n - 1)]);
+  }
+  float rmx[2][16];            // rowmax output: max |y| of this lane's 2 columns for each of its 32 rows
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + acc_row(wm, tm, r, lane);
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + acc_row(wm, tm, r, lane);
+      float ia = 1.f;
+      if (MMA == kMmaF16x3) {
+        const int64_t rc = min(row, g.m - 1);
+        float ma = g.amax0[rc];
+        if (g.amax1 != nullptr) ma = fmaxf(ma, g.amax1[rc]);
+        ia = f3_inv_scale(ma);
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int64_t col = col0 + acc_col(wn, tn, lane);
+        const float bv = (bias != nullptr && col < g.n) ? bias[col] : 0.f;
         if (row < g.m && col < g.n) {
-          float v = acc[tm][tn][r] + bv;
+          float v = (MMA == kMmaF16x3 ? acc[tm][tn][r] * (ia * ib[tn]) : acc[tm][tn][r]) + bv;
           if (RELU) v = fmaxf(v, 0.f);
           y[row * ldy + col] = v;
+          mx = fmaxf(mx, fabsf(v));
         }
       }
+      rmx[tm][r] = mx;
+    }
+  if (out_rowmax != nullptr) {
+    // Row maxima for the NEXT layer's operand scales: the 32 lanes of a half wave hold 32 columns of the same 32 rows; a halving
+    // butterfly (lane bit i <-> row-slot bit 4 - i; DPP inside quads, ds_swizzle across) leaves every lane with the maximum of
+    // ONE row over the wave's 64 columns, and one atomic max per lane (non-negative floats order like their bit patterns) merges
+    // the wave columns and column tiles.  out_rowmax must be zeroed before the launch.
+    const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8, lb4 = lane & 16;
+    float v16[16], v8[8], v4[4], v2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {       // slot = tm * 16 + r; bit 4 (tm) <-> lane bit 0
+      const float keep = lb0 ? rmx[1][i] : rmx[0][i], send = lb0 ? rmx[0][i] : rmx[1][i];
+      v16[i] = fmaxf(keep, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true)));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float keep = lb1 ? v16[i + 8] : v16[i], send = lb1 ? v16[i] : v16[i + 8];
+      v8[i] = fmaxf(keep, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true)));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float keep = lb2 ? v8[i + 4] : v8[i], send = lb2 ? v8[i] : v8[i + 4];
+      v4[i] = fmaxf(keep, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x101F)));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float keep = lb3 ? v4[i + 2] : v4[i], send = lb3 ? v4[i] : v4[i + 2];
+      v2[i] = fmaxf(keep, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x201F)));
+    }
+    const float keep = lb4 ? v2[1] : v2[0], send = lb4 ? v2[0] : v2[1];
+    const float mrow = fmaxf(keep, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F)));
+    const int slot = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+    const int64_t row = row0 + acc_row(wm, slot >> 4, slot & 15, lane);
+    if (row < g.m) atomicMax(reinterpret_cast<unsigned*>(out_rowmax + row), __float_as_uint(mrow));
   }
+}
+
+// max |x| of every row of a [rows, ld] matrix (the static operand scales of the weights; one wave per row)
+__global__ void __launch_bounds__(256) k_row_absmax(const float* __restrict__ src, int rows, int k, int64_t ld, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float m = 0.f;
+  for (int i = lane; i < k; i += 64) m = fmaxf(m, fabsf(src[(int64_t)row * ld + i]));
+  m = sdg_wave_max(m);
+  if (lane == 0) out[row] = m;
+}
+
+// upper bound of max |x| over the encoded ray input (a12): the raw coordinates, and 1 for the sin / cos features
+__global__ void __launch_bounds__(256) k_ray_input_bound(const float* __restrict__ ori, const float* __restrict__ dir, const float* __restrict__ rgb,
+                                                        int64_t R, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  float m = 1.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) m = fmaxf(m, fmaxf(fabsf(ori[3 * i + c]), fmaxf(fabsf(dir[3 * i + c]), fabsf(rgb[3 * i + c]))));
+  out[i] = m;
 }
 
 // Split-K for GEMMs with few output tiles and a long K (the camera-up CNN as im2col: M = images x positions <= a few hundred,
@@ -88,7 +158,20 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
 
 int resolve_mma(int mode) {
   if (mode == SIXDGS_MMA_F32) return mode;
-  return SIXDGS_MMA_BF16X6;  // DEFAULT, BF16X6 and F16X3 (the dense layers have no scaled-fp16 variant yet)
+  return SIXDGS_MMA_BF16X6;  // DEFAULT, BF16X6 and F16X3: generic GEMMs carry no row maxima, so no scaled-fp16 variant for them
+}
+
+// scaled fp16 x 3 (operands with row maxima: the ray MLP chain); out_rowmax (zeroed by the caller) receives max |y| per row
+int launch_linear_f3(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, float* out_rowmax, hipStream_t s) {
+  const int64_t m_tiles = sdg_cdiv(g.m, 128), n_tiles = sdg_cdiv(g.n, kBN);
+  const int64_t total = m_tiles * n_tiles;
+  if (total <= 0) return 0;
+  if (total > 0x7fffffffLL || !g.amax0 || !g.bmax) return SIXDGS_E_BADARG;
+  const dim3 grid((unsigned)total), blk(256);
+  if (relu) hipLaunchKernelGGL((k_linear<kMmaF16x3, true>), grid, blk, 0, s, g, bias, y, ldy, (unsigned)n_tiles, (unsigned)total, out_rowmax);
+  else hipLaunchKernelGGL((k_linear<kMmaF16x3, false>), grid, blk, 0, s, g, bias, y, ldy, (unsigned)n_tiles, (unsigned)total, out_rowmax);
+  SDG_LAUNCH_OK();
+  return 0;
 }
 
 int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y, int64_t ldy, hipStream_t s, int mma) {
@@ -99,11 +182,11 @@ int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y,
   const dim3 grid((unsigned)total), blk(256);
   const unsigned nt = (unsigned)n_tiles, tt = (unsigned)total;
   if (resolve_mma(mma) == SIXDGS_MMA_BF16X6) {
-    if (relu) hipLaunchKernelGGL((k_linear<kMmaBf16x6, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
-    else hipLaunchKernelGGL((k_linear<kMmaBf16x6, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+    if (relu) hipLaunchKernelGGL((k_linear<kMmaBf16x6, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt, (float*)nullptr);
+    else hipLaunchKernelGGL((k_linear<kMmaBf16x6, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt, (float*)nullptr);
   } else {
-    if (relu) hipLaunchKernelGGL((k_linear<kMmaF32, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
-    else hipLaunchKernelGGL((k_linear<kMmaF32, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt);
+    if (relu) hipLaunchKernelGGL((k_linear<kMmaF32, true>), grid, blk, 0, s, g, bias, y, ldy, nt, tt, (float*)nullptr);
+    else hipLaunchKernelGGL((k_linear<kMmaF32, false>), grid, blk, 0, s, g, bias, y, ldy, nt, tt, (float*)nullptr);
   }
   SDG_LAUNCH_OK();
   return 0;
@@ -190,9 +273,14 @@ constexpr size_t kOffWk = kOffB4 + pad64(384);
 constexpr size_t kOffBk = kOffWk + pad64(384 * 384);
 constexpr size_t kOffWq = kOffBk + pad64(384);
 constexpr size_t kOffBq = kOffWq + pad64(400 * 384);
-constexpr size_t kPackedFloats = kOffBq + pad64(384);
+constexpr size_t kOffM1 = kOffBq + pad64(384);      // max |w| of every row of W1 .. Wk (operand scales of the scaled-fp16 GEMMs)
+constexpr size_t kOffM2 = kOffM1 + pad64(512);
+constexpr size_t kOffM3 = kOffM2 + pad64(512);
+constexpr size_t kOffM4 = kOffM3 + pad64(512);
+constexpr size_t kOffMk = kOffM4 + pad64(384);
+constexpr size_t kPackedFloats = kOffMk + pad64(384);
 
-constexpr size_t kChunkFloatsPerRay = SIXDGS_RAY_IN_PAD + SIXDGS_HID + SIXDGS_HID;
+constexpr size_t kChunkFloatsPerRay = SIXDGS_RAY_IN_PAD + SIXDGS_HID + SIXDGS_HID + 3;    // x, h1, h2 + three row-maximum arrays
 
 }  // namespace
 
@@ -234,6 +322,14 @@ int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* m
   hipLaunchKernelGGL(k_pad_transpose, dim3((unsigned)sdg_cdiv(384 * 400, 256)), dim3(256), 0, s, qproj_w, 384, 398, 400,
                      packed + kOffWq);
   pad(qproj_b, 1, 384, 384, kOffBq);
+  auto rowmax = [&](size_t woff, int rows, int k, size_t moff) {
+    hipLaunchKernelGGL(k_row_absmax, dim3((unsigned)sdg_cdiv(rows, 4)), dim3(256), 0, s, packed + woff, rows, k, (int64_t)k, packed + moff);
+  };
+  rowmax(kOffW1, 512, 144, kOffM1);
+  rowmax(kOffW2, 512, 512, kOffM2);
+  rowmax(kOffW3, 512, 656, kOffM3);
+  rowmax(kOffW4, 384, 512, kOffM4);
+  rowmax(kOffWk, 384, 384, kOffMk);
   SDG_LAUNCH_OK();
   out->w1 = packed + kOffW1; out->b1 = packed + kOffB1;
   out->w2 = packed + kOffW2; out->b2 = packed + kOffB2;
@@ -241,6 +337,7 @@ int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* m
   out->w4 = packed + kOffW4; out->b4 = packed + kOffB4;
   out->wk = packed + kOffWk; out->bk = packed + kOffBk;
   out->wq = packed + kOffWq; out->bq = packed + kOffBq;
+  out->m1 = packed + kOffM1; out->m2 = packed + kOffM2; out->m3 = packed + kOffM3; out->m4 = packed + kOffM4; out->mk = packed + kOffMk;
   return 0;
 }
 
@@ -325,28 +422,59 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
   float* x = (float*)ws;
   float* h1 = x + chunk * SIXDGS_RAY_IN_PAD;
   float* h2 = h1 + chunk * SIXDGS_HID;
+  float* rmx = h2 + chunk * SIXDGS_HID;        // row maxima: encoded input, and two buffers that alternate through the layers
+  float* rma = rmx + chunk;
+  float* rmb = rma + chunk;
+  // the dense layers run scaled fp16 x 3 (row-scaled operands, 3 MFMA terms) in the default / F16X3 modes, bf16 x 6 or fp32 otherwise
+  const bool f3 = mma_mode == SIXDGS_MMA_DEFAULT || mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32;
   for (int64_t r0 = 0; r0 < r; r0 += chunk) {
     const int64_t m = (r - r0) < chunk ? (r - r0) : chunk;
     // algorithmic work per ray: ray MLP 1 730 560 + k_proj 294 912 FLOP; 36 B in, 1536 B key out
     SdgProfileScope scope(prof, s, (double)m * ((key || key_planes) ? 2025472.0 : 1730560.0), (double)m * (36.0 + 1536.0));
     int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
     if (st) return st;
-    GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
-    if ((st = launch_linear(g1, w->b1, true, h1, SIXDGS_HID, s, mma_mode))) return st;
-    GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID};
-    if ((st = launch_linear(g2, w->b2, true, h2, SIXDGS_HID, s, mma_mode))) return st;
-    // layer 3 consumes the concatenation [h2, x] without materialising it (two A segments)
-    GemmOperands g3 = {h2, x, w->w3, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_HID + SIXDGS_RAY_IN_PAD, m, SIXDGS_HID,
-                       SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID};
-    if ((st = launch_linear(g3, w->b3, true, h1, SIXDGS_HID, s, mma_mode))) return st;
     float* f = feat ? feat + r0 * SIXDGS_D : h2;
-    GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID};
-    if ((st = launch_linear(g4, w->b4, false, f, SIXDGS_D, s, mma_mode))) return st;
-    if (key || key_planes) {
-      // without a caller buffer for fp32 keys the chunk lands in h1 (free after layer 4) and only the planes persist
-      float* kdst = key ? key + r0 * SIXDGS_D : h1;
-      GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
-      if ((st = launch_linear(g5, w->bk, false, kdst, SIXDGS_D, s, mma_mode))) return st;
+    // without a caller buffer for fp32 keys the chunk lands in h1 (free after layer 4) and only the planes persist
+    float* kdst = key ? key + r0 * SIXDGS_D : h1;
+    const bool want_key = key || key_planes;
+    if (f3) {
+      hipLaunchKernelGGL(k_ray_input_bound, dim3((unsigned)sdg_cdiv(m, 256)), dim3(256), 0, s, ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, rmx);
+      auto zero = [&](float* p) { return hipMemsetAsync(p, 0, (size_t)m * sizeof(float), s); };
+      if (zero(rma) != hipSuccess) return (int)hipGetLastError();
+      GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD, rmx, nullptr, w->m1};
+      if ((st = launch_linear_f3(g1, w->b1, true, h1, SIXDGS_HID, rma, s))) return st;
+      if (zero(rmb) != hipSuccess) return (int)hipGetLastError();
+      GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID, rma, nullptr, w->m2};
+      if ((st = launch_linear_f3(g2, w->b2, true, h2, SIXDGS_HID, rmb, s))) return st;
+      // layer 3 consumes the concatenation [h2, x] without materialising it (two A segments, one scale per row for both)
+      if (zero(rma) != hipSuccess) return (int)hipGetLastError();
+      GemmOperands g3 = {h2, x, w->w3, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_HID + SIXDGS_RAY_IN_PAD, m, SIXDGS_HID,
+                         SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID, rmb, rmx, w->m3};
+      if ((st = launch_linear_f3(g3, w->b3, true, h1, SIXDGS_HID, rma, s))) return st;
+      if (zero(rmb) != hipSuccess) return (int)hipGetLastError();
+      GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID, rma, nullptr, w->m4};
+      if ((st = launch_linear_f3(g4, w->b4, false, f, SIXDGS_D, want_key ? rmb : nullptr, s))) return st;
+      if (want_key) {
+        GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D, rmb, nullptr, w->mk};
+        if ((st = launch_linear_f3(g5, w->bk, false, kdst, SIXDGS_D, nullptr, s))) return st;
+      }
+    } else {
+      GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
+      if ((st = launch_linear(g1, w->b1, true, h1, SIXDGS_HID, s, mma_mode))) return st;
+      GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID};
+      if ((st = launch_linear(g2, w->b2, true, h2, SIXDGS_HID, s, mma_mode))) return st;
+      // layer 3 consumes the concatenation [h2, x] without materialising it (two A segments)
+      GemmOperands g3 = {h2, x, w->w3, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_HID + SIXDGS_RAY_IN_PAD, m, SIXDGS_HID,
+                         SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID};
+      if ((st = launch_linear(g3, w->b3, true, h1, SIXDGS_HID, s, mma_mode))) return st;
+      GemmOperands g4 = {h1, nullptr, w->w4, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_D, SIXDGS_HID, SIXDGS_HID};
+      if ((st = launch_linear(g4, w->b4, false, f, SIXDGS_D, s, mma_mode))) return st;
+      if (want_key) {
+        GemmOperands g5 = {f, nullptr, w->wk, SIXDGS_D, 0, SIXDGS_D, m, SIXDGS_D, SIXDGS_D, SIXDGS_D};
+        if ((st = launch_linear(g5, w->bk, false, kdst, SIXDGS_D, s, mma_mode))) return st;
+      }
+    }
+    if (want_key) {
       if (f16) st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
       else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
       if (st) return st;

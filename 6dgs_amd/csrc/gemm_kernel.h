@@ -36,6 +36,10 @@ struct GemmOperands {
   int64_t lda0, lda1, ldb;
   int64_t m, n;      // valid rows of A / rows of B
   int k, k0;         // total K (multiple of 4), K0 (multiple of 32 when a1 != null, else == k)
+  // scaled-fp16 x 3 variant only: an upper bound of max|.| of every operand row (within 2x of the true maximum)
+  const float* amax0;   // [M] for segment a0
+  const float* amax1;   // [M] for segment a1 (or null)
+  const float* bmax;    // [N]
 };
 
 // bijective XCD-aware remap: consecutive work items land on the same XCD (block b runs on XCD b % 8),
@@ -270,14 +274,130 @@ __device__ __forceinline__ void gemm_mainloop_b6(const GemmOperands& g, int64_t 
   }
 }
 
-constexpr int kMmaF32 = 0, kMmaBf16x6 = 1;
+// ------------------------------------------------------------------------------------------------
+// scaled fp16 x 3 variant (the dense layers of the ray MLP, round 2): the arithmetic of the scorer's logits kernel -- every operand
+// ROW multiplied by the power of two that puts its largest magnitude in [2^13, 2^14), split into two fp16 planes x 2^s = h + l
+// (22 significant bits for everything within 2^-17 of the row maximum, an absolute error <= 2^-38 of the row maximum below that),
+// three cross terms l*h + h*l + h*h on v_mfma_f32_32x32x16_f16 -- with the split done on the fly like the bf16 x 6 variant.  Half
+// the MFMA instructions and two thirds of the LDS bytes of bf16 x 6; measured error 1.0e-7 * sum|a||b| (tools/probe_f16x3.py).
+// The row maxima come with the operands (GemmOperands::amax0 / amax1 / bmax): the producing layer's epilogue leaves them
+// (k_linear's rowmax output), the weights' are computed when they are packed.  The caller undoes the scales per output element:
+// f3_inv_scale(row maximum of A) * f3_inv_scale(row maximum of B).
+// LDS image of a slab: per row 2 planes x 32 fp16 = 2 x 64 B, row stride 144 B (9 x 16 B: odd multiple of the 16-byte slot).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+constexpr int kF3Row = 144;
+constexpr int kF3Bytes = (128 + kBN) * kF3Row;
+
+// sh with m * 2^sh in [2^13, 2^14) for a normal m > 0 (clamped to +-100; m == 0 gives 2^100, harmless)
+__device__ __forceinline__ int f3_shift(float m) {
+  const int eb = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  const int sh = 140 - eb;
+  return sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+}
+__device__ __forceinline__ float f3_scale(float m) { return __uint_as_float((unsigned)(127 + f3_shift(m)) << 23); }
+__device__ __forceinline__ float f3_inv_scale(float m) { return __uint_as_float((unsigned)(127 - f3_shift(m)) << 23); }
+
+__device__ __forceinline__ void f3_split_store8(const float4& lo, const float4& hi, float sc, char* dst) {
+  const float x[8] = {lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc};
+  f16x8_t h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 hh = (_Float16)x[e];
+    h[e] = hh;
+    l[e] = (_Float16)(x[e] - (float)hh);
+  }
+  *reinterpret_cast<f16x8_t*>(dst) = h;
+  *reinterpret_cast<f16x8_t*>(dst + 64) = l;
+}
+
+__device__ __forceinline__ void gemm_mainloop_f3(const GemmOperands& g, int64_t row0, int64_t col0, char* smem, f32x16 (&acc)[2][2]) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 2, lchunk = tid & 3;   // loader: 4 lanes x 32 B cover one 128-B row segment
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the four operand rows this thread stages (two of A, two of B) keep their scale for the whole contraction
+  float sca[2], scb[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int64_t ra_ = min(row0 + p * 64 + lrow, g.m - 1), rb_ = min(col0 + p * 64 + lrow, g.n - 1);
+    float ma = g.amax0[ra_];
+    if (g.amax1 != nullptr) ma = fmaxf(ma, g.amax1[ra_]);
+    sca[p] = f3_scale(ma);
+    scb[p] = f3_scale(g.bmax[rb_]);
+  }
+
+  float4 ra[2][2], rb[2][2];
+  const int nslab = (g.k + kBK - 1) / kBK;
+  auto load_slab = [&](int s) {
+    const int kk = s * kBK + lchunk * 8;
+    const bool seg1 = g.a1 != nullptr && kk >= g.k0;
+    const float* abase = seg1 ? g.a1 : g.a0;
+    const int64_t lda = seg1 ? g.lda1 : g.lda0;
+    const int ka = seg1 ? kk - g.k0 : kk;
+    const bool k0ok = kk < g.k, k1ok = kk + 4 < g.k;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      ra[p][0] = load4_guarded(abase, row0 + p * 64 + lrow, g.m, lda, ka, k0ok);
+      ra[p][1] = load4_guarded(abase, row0 + p * 64 + lrow, g.m, lda, ka + 4, k1ok);
+      rb[p][0] = load4_guarded(g.b, col0 + p * 64 + lrow, g.n, g.ldb, kk, k0ok);
+      rb[p][1] = load4_guarded(g.b, col0 + p * 64 + lrow, g.n, g.ldb, kk + 4, k1ok);
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f3_split_store8(ra[p][0], ra[p][1], sca[p], smem + (p * 64 + lrow) * kF3Row + lchunk * 16);
+      f3_split_store8(rb[p][0], rb[p][1], scb[p], smem + (128 + p * 64 + lrow) * kF3Row + lchunk * 16);
+    }
+  };
+
+  load_slab(0);
+  const char* sa = smem + (wm * 64 + (lane & 31)) * kF3Row + (lane >> 5) * 16;
+  const char* sb = smem + (128 + wn * 64 + (lane & 31)) * kF3Row + (lane >> 5) * 16;
+  for (int s = 0; s < nslab; ++s) {
+    store_slab();
+    __syncthreads();
+    if (s + 1 < nslab) load_slab(s + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8_t a[2][2], b[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          a[t][p] = *reinterpret_cast<const f16x8_t*>(sa + t * 32 * kF3Row + p * 64 + ks * 32);
+          b[t][p] = *reinterpret_cast<const f16x8_t*>(sb + t * 32 * kF3Row + p * 64 + ks * 32);
+        }
+      constexpr int PA[3] = {1, 0, 0};   // (A plane, B plane): l*h, h*l, h*h -- smallest magnitude first
+      constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][PA[q]], b[0][PB[q]], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][PA[q]], b[1][PB[q]], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][PA[q]], b[0][PB[q]], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][PA[q]], b[1][PB[q]], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kMmaF32 = 0, kMmaBf16x6 = 1, kMmaF16x3 = 2;
 template <int MMA>
 struct TileSmem {
-  static constexpr int kBytes = MMA == kMmaBf16x6 ? kB6Bytes : GemmSmem<2>::kBytes;
+  static constexpr int kBytes = MMA == kMmaBf16x6 ? kB6Bytes : (MMA == kMmaF16x3 ? kF3Bytes : GemmSmem<2>::kBytes);
 };
 template <int MMA>
 __device__ __forceinline__ void gemm_tile(const GemmOperands& g, int64_t row0, int64_t col0, char* smem, f32x16 (&acc)[2][2]) {
   if constexpr (MMA == kMmaBf16x6) gemm_mainloop_b6(g, row0, col0, smem, acc);
+  else if constexpr (MMA == kMmaF16x3) gemm_mainloop_f3(g, row0, col0, smem, acc);
   else gemm_mainloop<2>(g, row0, col0, reinterpret_cast<float*>(smem), acc);
 }
 

@@ -169,6 +169,12 @@ typedef struct sixdgs_scorer_weights {
   const float* bk;
   const float* wq; /* [384][400]  attention.q_proj (cols 398,399 zero) */
   const float* bq;
+  /* max |w| of every row of w1 .. wk: the static operand scales of the scaled-fp16 x 3 dense layers (SIXDGS_MMA_DEFAULT / F16X3) */
+  const float* m1; /* [512] */
+  const float* m2; /* [512] */
+  const float* m3; /* [512] */
+  const float* m4; /* [384] */
+  const float* mk; /* [384] */
 } sixdgs_scorer_weights;
 
 size_t sixdgs_packed_weights_floats(void);
