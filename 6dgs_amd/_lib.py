@@ -29,7 +29,7 @@ class Profile(C.Structure):
 
 
 class ScorerWeights(C.Structure):
-    _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wk", "bk", "wq", "bq", "m1", "m2", "m3", "m4", "mk")]
+    _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wk", "bk", "wq", "bq", "m1", "m2", "m3", "m4", "mk", "planes")]
 
 
 # name -> (restype, argtypes); mirrors include/sixdgs.h one to one

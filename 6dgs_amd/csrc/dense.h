@@ -1,0 +1,15 @@
+// dense.h -- internal interface between gemm.hip (weight packing, sixdgs_ray_keys_ex) and dense.hip (the plane-to-plane ray MLP chain)
+#pragma once
+#include "common.h"
+
+namespace sdg {
+// bytes of the pre-split weight planes of the five ray-side layers (appended to the packed weight buffer)
+size_t dense_weight_plane_bytes();
+// fp32 weights + row maxima of `w` (already packed) -> scaled fp16 planes
+int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipStream_t s);
+// scratch bytes per ray of dense_chain
+size_t dense_chain_bytes_per_ray();
+// rays -> fp32 keys kdst [m][384] through the plane-to-plane layers
+int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* ws,
+                hipStream_t s);
+}  // namespace sdg

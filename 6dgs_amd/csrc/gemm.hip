@@ -3,6 +3,7 @@
 // kernel of gemm_kernel.h with bias/ReLU fused into the epilogue.
 #include "gemm_kernel.h"
 #include "device_math.h"
+#include "dense.h"
 
 using namespace sdg;
 
@@ -278,9 +279,13 @@ constexpr size_t kOffM2 = kOffM1 + pad64(512);
 constexpr size_t kOffM3 = kOffM2 + pad64(512);
 constexpr size_t kOffM4 = kOffM3 + pad64(512);
 constexpr size_t kOffMk = kOffM4 + pad64(384);
-constexpr size_t kPackedFloats = kOffMk + pad64(384);
+constexpr size_t kOffPlanes = kOffMk + pad64(384);  // scaled fp16 planes of W1 .. Wk for the plane-to-plane chain (dense.hip)
+constexpr size_t kPlaneFloats = (512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12) * 32;
+constexpr size_t kPackedFloats = kOffPlanes + pad64(kPlaneFloats);
 
-constexpr size_t kChunkFloatsPerRay = SIXDGS_RAY_IN_PAD + SIXDGS_HID + SIXDGS_HID + 3;    // x, h1, h2 + three row-maximum arrays
+// per ray of a chunk: fp32-operand chain x, h1, h2 + three row-maximum arrays = 1171 floats; plane-to-plane chain fp32 keys (384 floats)
+// + planes and shifts (4776 B): the larger of the two
+constexpr size_t kChunkFloatsPerRay = 1580;
 
 }  // namespace
 
@@ -338,7 +343,8 @@ int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* m
   out->wk = packed + kOffWk; out->bk = packed + kOffBk;
   out->wq = packed + kOffWq; out->bq = packed + kOffBq;
   out->m1 = packed + kOffM1; out->m2 = packed + kOffM2; out->m3 = packed + kOffM3; out->m4 = packed + kOffM4; out->mk = packed + kOffMk;
-  return 0;
+  out->planes = packed + kOffPlanes;
+  return dense_pack_weight_planes(out, reinterpret_cast<char*>(packed + kOffPlanes), s);
 }
 
 int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int64_t r, float* x, sixdgs_stream_t stream) {
@@ -431,13 +437,20 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
     const int64_t m = (r - r0) < chunk ? (r - r0) : chunk;
     // algorithmic work per ray: ray MLP 1 730 560 + k_proj 294 912 FLOP; 36 B in, 1536 B key out
     SdgProfileScope scope(prof, s, (double)m * ((key || key_planes) ? 2025472.0 : 1730560.0), (double)m * (36.0 + 1536.0));
-    int st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream);
-    if (st) return st;
+    int st = 0;
     float* f = feat ? feat + r0 * SIXDGS_D : h2;
     // without a caller buffer for fp32 keys the chunk lands in h1 (free after layer 4) and only the planes persist
-    float* kdst = key ? key + r0 * SIXDGS_D : h1;
+    float* kdst = key ? key + r0 * SIXDGS_D : h1;     // (the plane-to-plane chain below redirects it)
     const bool want_key = key || key_planes;
-    if (f3) {
+    if (f3 && want_key && !feat && w->planes) {
+      // plane-to-plane chain (dense.hip): no fp32 activation through HBM, nothing split in a main loop; fp32 keys land in the
+      // caller's buffer or at the head of the workspace, the planes and shifts of the layers behind them
+      float* kd = key ? key + r0 * SIXDGS_D : x;
+      char* pws = reinterpret_cast<char*>(x + (size_t)chunk * SIXDGS_D);
+      if ((st = dense_chain(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, w, reinterpret_cast<const char*>(w->planes), kd, pws, s))) return st;
+      kdst = kd;
+    } else if (f3) {
+      if ((st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream))) return st;
       hipLaunchKernelGGL(k_ray_input_bound, dim3((unsigned)sdg_cdiv(m, 256)), dim3(256), 0, s, ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, rmx);
       auto zero = [&](float* p) { return hipMemsetAsync(p, 0, (size_t)m * sizeof(float), s); };
       if (zero(rma) != hipSuccess) return (int)hipGetLastError();
@@ -459,6 +472,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
         if ((st = launch_linear_f3(g5, w->bk, false, kdst, SIXDGS_D, nullptr, s))) return st;
       }
     } else {
+      if ((st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream))) return st;
       GemmOperands g1 = {x, nullptr, w->w1, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, m, SIXDGS_HID, SIXDGS_RAY_IN_PAD, SIXDGS_RAY_IN_PAD};
       if ((st = launch_linear(g1, w->b1, true, h1, SIXDGS_HID, s, mma_mode))) return st;
       GemmOperands g2 = {h1, nullptr, w->w2, SIXDGS_HID, 0, SIXDGS_HID, m, SIXDGS_HID, SIXDGS_HID, SIXDGS_HID};

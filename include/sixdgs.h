@@ -175,6 +175,8 @@ typedef struct sixdgs_scorer_weights {
   const float* m3; /* [512] */
   const float* m4; /* [384] */
   const float* mk; /* [384] */
+  const void* planes; /* w1 .. wk pre-split into scaled fp16 planes [row][k-slabs][2][32] (w3 as [h | x padded to 160]): the operands of the
+                         plane-to-plane ray MLP chain that sixdgs_ray_keys_ex runs when only keys / key planes are asked for */
 } sixdgs_scorer_weights;
 
 size_t sixdgs_packed_weights_floats(void);

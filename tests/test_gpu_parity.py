@@ -240,8 +240,14 @@ def scorer(request, ops, oracle, golden, syn):
         # the planes written chunk by chunk behind k_proj are those of a single split pass over the finished keys
         p2, s2 = ops.split_planes_f16(key)
         assert torch.equal(p2, planes) and torch.equal(s2, kscale)
+        # without a feature output the f16x3 modes run the plane-to-plane chain (dense.hip): chunking must be invisible there too
+        _, kfast, (p4, s4) = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_planes=True)
         _, _, (p3, s3) = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_key=False, want_planes=True, max_chunk=1024)
-        assert torch.equal(p3, planes) and torch.equal(s3, kscale)
+        assert torch.equal(p3, p4) and torch.equal(s3, s4)
+        p5, s5 = ops.split_planes_f16(kfast)
+        assert torch.equal(p5, p4) and torch.equal(s5, s4)
+        assert rel_err(N(kfast), okey) < 5e-6                 # the chain's keys against the oracle ...
+        assert rel_err(N(kfast), N(key)) < 2e-6               # ... and against the fp32-operand kernels' keys
     return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey, mode=request.param,
                 planes=planes if request.param != "f32" else None, kscale=kscale)
 
@@ -292,9 +298,13 @@ def test_a13_ray_features_and_keys(scorer):
 
 def test_ray_keys_chunked_equals_unchunked(ops, scorer):
     r = scorer["rays"]
-    ws = torch.empty(1000 * (144 + 512 + 512) * 4, dtype=torch.uint8, device="cuda")   # forces ~900-ray chunks
+    ws = torch.empty(1000 * 1580 * 4, dtype=torch.uint8, device="cuda")   # forces ~900-ray chunks (896: whole 128-ray scale tiles)
     _, key2 = ops.ray_keys(G(r["ori"]), G(r["dir"]), G(r["rgb"]), scorer["w"], workspace=ws, max_chunk=1000)
-    assert torch.equal(key2, scorer["key"])
+    _, key1 = ops.ray_keys(G(r["ori"]), G(r["dir"]), G(r["rgb"]), scorer["w"])
+    assert torch.equal(key2, key1)
+    assert rel_err(N(key2), scorer["okey"]) < 5e-6
+    fb, kb = ops.ray_keys(G(r["ori"]), G(r["dir"]), G(r["rgb"]), scorer["w"], workspace=ws, max_chunk=1000, want_feat=True)
+    assert torch.equal(kb, scorer["key"]) and torch.equal(fb, scorer["feat"])
 
 
 @pytest.mark.parametrize("tag,T,scale", [("flat256", 256, 1.0), ("peaky256", 256, 40.0), ("peaky137", 137, 40.0),
@@ -639,3 +649,19 @@ def test_geometry_randomised_against_the_oracle(ops, oracle):
             d = N(ops.isocell_distribution(tgt, n0))
             od = oracle.isocell_distribution(tgt, n0)
             assert d.shape == od.shape and np.abs(d - od).max() < 2e-6, (tgt, n0)
+
+
+def test_plane_chain_keys_on_wide_dynamic_range_inputs(ops, oracle, syn):
+    """The plane-to-plane ray MLP chain (scaled fp16 x 3, one scale per ray and block of 128 features) on rays whose coordinates span
+    six orders of magnitude and on a ragged ray count: keys against the oracle's fp32 chain."""
+    sd = syn.make_scorer_state_dict(3)
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
+    rays = syn.make_rays(5003, 9)
+    rays["ori"] = (rays["ori"] * np.logspace(-3, 3, 5003)[:, None]).astype(np.float32)
+    rays["rgb"][::7] = 0.0
+    _, key = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w)
+    _, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
+    assert bool(torch.isfinite(key).all())
+    # row-wise: every key row within 5e-6 of its own largest element
+    err = np.abs(N(key) - okey).max(axis=1) / np.abs(okey).max(axis=1)
+    assert err.max() < 5e-6, err.max()
