@@ -74,55 +74,77 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // loader: thread -> (row = tid >> 1, plane = tid & 1): 64 B of one plane of one row per operand and slab
-  const int lrow = tid >> 1, lpl = tid & 1;
-  const int64_t lray = min(ray0 + lrow, A.m - 1);
-  const char* wsrc = A.wp + ((int64_t)(f0 + lrow) * ks) * kSlabB + lpl * 64;
-  const char* asrc0 = A.a0 + (lray * A.ks0) * kSlabB + lpl * 64;
-  const char* asrc1 = A.a1 ? A.a1 + (lray * A.ks1) * kSlabB + lpl * 64 : nullptr;
-  uint4 rw[4], ra[4];
-  auto load_slab = [&](int s) {
-    const char* ws_ = wsrc + (int64_t)s * kSlabB;
-    const char* as_ = s < A.ks0 ? asrc0 + (int64_t)s * kSlabB : asrc1 + (int64_t)(s - A.ks0) * kSlabB;
+  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab) -- every wave instruction reads 8 FULL cache lines (a lane reading 64
+  // contiguous bytes of its own row touches 32 lines per instruction); 4 instructions x 32 rows per operand.  Row offsets are 32-bit
+  // (a chunk's planes stay below 4 GB) against uniform bases; the loads are unconditional (the last iteration re-reads the last slab):
+  // with a conditional load hipcc kept the staging registers in scratch and waited for every load right behind its issue.
+  const int lrow = tid >> 3, lc8 = tid & 7;
+  unsigned woff[4], aoff0[4], aoff1[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      rw[c] = *reinterpret_cast<const uint4*>(ws_ + c * 16);
-      ra[c] = *reinterpret_cast<const uint4*>(as_ + c * 16);
-    }
-  };
-  auto store_slab = [&](int buf) {
-    char* dw = smem + buf * kPStage + lrow * kPRow + lpl * 64;
-    char* da = dw + 128 * kPRow;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<uint4*>(dw + c * 16) = rw[c];
-      *reinterpret_cast<uint4*>(da + c * 16) = ra[c];
-    }
-  };
-
-  // this lane's two rays (column tiles tn = 0, 1) and their running shift
-  int64_t cray[2];
-  int sh_cur[2];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    cray[tn] = min(ray0 + wn * 64 + tn * 32 + (lane & 31), A.m - 1);
-    sh_cur[tn] = A.s0[cray[tn] * A.g0];
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lray = (unsigned)min((int64_t)(i * 32 + lrow), A.m - 1 - ray0);        // ray within the tile, clamped to the last valid one
+    woff[i] = (unsigned)((i * 32 + lrow) * ks) * kSlabB + lc8 * 16;
+    aoff0[i] = (lray * (unsigned)A.ks0) * kSlabB + lc8 * 16;
+    aoff1[i] = (lray * (unsigned)A.ks1) * kSlabB + lc8 * 16;
+  }
+  const char* wbase = A.wp + ((int64_t)f0 * ks) * kSlabB;
+  const char* abase0 = A.a0 + (ray0 * A.ks0) * kSlabB;
+  const char* abase1 = A.a1 ? A.a1 + (ray0 * A.ks1) * kSlabB : abase0;
+  uint4 rw0, rw1, rw2, rw3, ra0, ra1, ra2, ra3;
+#define SDG_LOAD_SLAB(S)                                                                                   \
+  {                                                                                                          \
+    const int s_ = (S) < ks ? (S) : ks - 1;                                                                  \
+    const bool seg1_ = s_ >= A.ks0;                                                                          \
+    const char* wb_ = wbase + (unsigned)s_ * kSlabB;                                                         \
+    const char* ab_ = seg1_ ? abase1 + (unsigned)(s_ - A.ks0) * kSlabB : abase0 + (unsigned)s_ * kSlabB;     \
+    rw0 = *reinterpret_cast<const uint4*>(wb_ + woff[0]);                                                    \
+    rw1 = *reinterpret_cast<const uint4*>(wb_ + woff[1]);                                                    \
+    rw2 = *reinterpret_cast<const uint4*>(wb_ + woff[2]);                                                    \
+    rw3 = *reinterpret_cast<const uint4*>(wb_ + woff[3]);                                                    \
+    ra0 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[0] : aoff0[0]));                              \
+    ra1 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[1] : aoff0[1]));                              \
+    ra2 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[2] : aoff0[2]));                              \
+    ra3 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[3] : aoff0[3]));                              \
+  }
+#define SDG_STORE_SLAB(BUF)                                                   \
+  {                                                                             \
+    char* dw_ = smem + (BUF) * kPStage + lrow * kPRow + lc8 * 16;               \
+    *reinterpret_cast<uint4*>(dw_) = rw0;                                       \
+    *reinterpret_cast<uint4*>(dw_ + 32 * kPRow) = rw1;                          \
+    *reinterpret_cast<uint4*>(dw_ + 64 * kPRow) = rw2;                          \
+    *reinterpret_cast<uint4*>(dw_ + 96 * kPRow) = rw3;                          \
+    *reinterpret_cast<uint4*>(dw_ + 128 * kPRow) = ra0;                         \
+    *reinterpret_cast<uint4*>(dw_ + 160 * kPRow) = ra1;                         \
+    *reinterpret_cast<uint4*>(dw_ + 192 * kPRow) = ra2;                         \
+    *reinterpret_cast<uint4*>(dw_ + 224 * kPRow) = ra3;                         \
   }
 
-  load_slab(0);
-  store_slab(0);
+  // this lane's two rays (column tiles tn = 0, 1) and the shifts of all their input blocks (<= 6: fetched once, not inside the loop)
+  constexpr int kMaxGroups = 6;
+  int shg[2][kMaxGroups];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t cray = min(ray0 + wn * 64 + tn * 32 + (lane & 31), A.m - 1);
+#pragma unroll
+    for (int g = 0; g < kMaxGroups; ++g)
+      shg[tn][g] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
+  }
+
+  SDG_LOAD_SLAB(0)
+  SDG_STORE_SLAB(0)
   __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;
   for (int s = 0; s < ks; ++s) {
     const int buf = s & 1;
-    if (s + 1 < ks) load_slab(s + 1);
+    SDG_LOAD_SLAB(s + 1)
     if ((s & 3) == 0 && s > 0) {       // a new block of 128 input features: bring the accumulators to its scale (exact)
       const int g = s >> 2;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const int shn = g < A.g0 ? A.s0[cray[tn] * A.g0 + g] : A.s1[cray[tn] * A.g1 + (g - A.g0)];
-        const float fac = pow2i(shn - sh_cur[tn]);
-        sh_cur[tn] = shn;
+        int d = 0;
+#pragma unroll
+        for (int gg = 1; gg < kMaxGroups; ++gg) d = gg == g ? shg[tn][gg] - shg[tn][gg - 1] : d;     // selects, no dynamic register indexing
+        const float fac = pow2i(d);
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -151,27 +173,42 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][PA[q]], b[1][PB[q]], acc[1][1], 0, 0, 0);
       }
     }
-    if (s + 1 < ks) store_slab(buf ^ 1);
+    SDG_STORE_SLAB(buf ^ 1)            // (after the last slab: a harmless copy into the idle stage)
     __syncthreads();
   }
+#undef SDG_LOAD_SLAB
+#undef SDG_STORE_SLAB
 
   // ---- epilogue.  Lane: rays (tn) x features f0 + wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
   float v[2][2][16];
   float rmax[2] = {0.f, 0.f};
+  const int glast = (ks - 1) >> 2;
+  float ib[2];
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
-    const float ib = pow2i(-sh_cur[tn]);
+    int shl = 0;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = f0 + wm * 64 + tm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        float x = acc[tm][tn][r] * (f3_inv_scale(A.wmax[f]) * ib) + A.bias[f];
-        if (A.relu) x = fmaxf(x, 0.f);
-        v[tn][tm][r] = x;
-        rmax[tn] = fmaxf(rmax[tn], fabsf(x));
-      }
+    for (int gg = 0; gg < kMaxGroups; ++gg) shl = gg == glast ? shg[tn][gg] : shl;
+    ib[tn] = pow2i(-shl);
   }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int fb = f0 + wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);                 // 4 consecutive features: 16-byte loads of their constants
+      const float4 wm4 = *reinterpret_cast<const float4*>(A.wmax + fb), b4 = *reinterpret_cast<const float4*>(A.bias + fb);
+      const float iw[4] = {f3_inv_scale(wm4.x), f3_inv_scale(wm4.y), f3_inv_scale(wm4.z), f3_inv_scale(wm4.w)};
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          float x = acc[tm][tn][4 * rg + j] * (iw[j] * ib[tn]) + bb[j];
+          if (A.relu) x = fmaxf(x, 0.f);
+          v[tn][tm][4 * rg + j] = x;
+          rmax[tn] = fmaxf(rmax[tn], fabsf(x));
+        }
+    }
   if (A.out_f32 != nullptr) {
     // fp32 rows through the staging tile [ray][128 features] (64 KiB), then 16-byte pieces: 512 contiguous bytes per ray
     float* st = reinterpret_cast<float*>(smem);

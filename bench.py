@@ -258,7 +258,7 @@ def main():
         step(None)
     elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
     l_ms, l_fl, l_by, l_n = prof.collect()
-    path = getattr(idm, "last_scoring_path", "two-pass") if not streamed else "streamed two-pass"
+    path = getattr(idm, "last_scoring_path", "two-pass")
     cand = list(getattr(idm, "last_select_candidates", [])) if use_select else None
 
     mode = ops.effective_mma_mode()
