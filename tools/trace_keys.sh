@@ -1,0 +1,17 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2l; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $R/tools/time_keys.py 4194304 > $O/time_keys.log 2> $O/trace.err
+DB=$(find $O/trace -name "*.db" | head -1)
+python - <<PY
+import sqlite3
+db=sqlite3.connect("$DB"); cur=db.cursor()
+rows=list(cur.execute("select name, grid_x, count(*), avg(duration), sum(duration) from kernels where name like '%k_dense%' or name like '%k_ray_encode%' or name like '%k_split_tiles%' or name like '%k_linear%' group by name, grid_x order by sum(duration) desc"))
+for r in rows[:20]: print(r[0][:60], r[1], r[2], round(r[3]/1e3,1),'us avg', round(r[4]/1e6,2),'ms total')
+# the five layers of one chunk in launch order (layer = position within each group of 5 k_dense_planes launches)
+seq=[r[0] for r in cur.execute("select duration from kernels where name like '%k_dense_planes%' order by start")]
+n=len(seq)//5
+for l in range(5):
+    v=sorted(seq[l::5][n//2:])            # second half of the launches: warm
+    print('layer', l+1, 'median', round(v[len(v)//2]/1e3,1), 'us')
+PY
+rm -rf $O/trace
