@@ -57,137 +57,10 @@ struct DenseArgs {
   int relu;
 };
 
-// One workgroup = one tile of 128 rays, ALL feature blocks of the layer one after the other: the per-workgroup set-up (shifts, offsets,
-// launch) is paid once per ray tile, and the first operand slab of block j + 1 is fetched while block j's epilogue runs (measured with
-// one workgroup per (ray tile, block): 14 us of fixed cost per tile against 1.4 us per k-slab -- 39 % of a 16-slab layer).
-__global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n_blocks, unsigned total_tiles) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kPStage];      // 73 728 B: two slab stages; the epilogue staging aliases them
-  __shared__ float wmaxs[2][128];                                      // per-ray maxima of the two feature waves
-  const unsigned w = xcd_remap(blockIdx.x, total_tiles);
-  const int64_t ray0 = (int64_t)w * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;               // wm: feature half (MFMA rows), wn: ray half (MFMA columns)
-  const int ks = A.ks0 + A.ks1;
-  f32x16 acc[2][2];
-
-  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab) -- every wave instruction reads 8 FULL cache lines (a lane reading 64
-  // contiguous bytes of its own row touches 32 lines per instruction); 4 instructions x 32 rows per operand.  Row offsets are 32-bit
-  // (a chunk's planes stay below 4 GB) against uniform bases; the loads are unconditional (the last iteration re-reads the last slab):
-  // with a conditional load hipcc kept the staging registers in scratch and waited for every load right behind its issue.
-  const int lrow = tid >> 3, lc8 = tid & 7;
-  unsigned woff[4], aoff0[4], aoff1[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lray = (unsigned)min((int64_t)(i * 32 + lrow), A.m - 1 - ray0);        // ray within the tile, clamped to the last valid one
-    woff[i] = (unsigned)((i * 32 + lrow) * ks) * kSlabB + lc8 * 16;
-    aoff0[i] = (lray * (unsigned)A.ks0) * kSlabB + lc8 * 16;
-    aoff1[i] = (lray * (unsigned)A.ks1) * kSlabB + lc8 * 16;
-  }
-  const char* wbase = A.wp;
-  const char* abase0 = A.a0 + (ray0 * A.ks0) * kSlabB;
-  const char* abase1 = A.a1 ? A.a1 + (ray0 * A.ks1) * kSlabB : abase0;
-  uint4 rw0, rw1, rw2, rw3, ra0, ra1, ra2, ra3;
-#define SDG_LOAD_SLAB(S)                                                                                   \
-  {                                                                                                          \
-    const int s_ = (S) < ks ? (S) : ks - 1;                                                                  \
-    const bool seg1_ = s_ >= A.ks0;                                                                          \
-    const char* wb_ = wbase + (unsigned)s_ * kSlabB;                                                         \
-    const char* ab_ = seg1_ ? abase1 + (unsigned)(s_ - A.ks0) * kSlabB : abase0 + (unsigned)s_ * kSlabB;     \
-    rw0 = *reinterpret_cast<const uint4*>(wb_ + woff[0]);                                                    \
-    rw1 = *reinterpret_cast<const uint4*>(wb_ + woff[1]);                                                    \
-    rw2 = *reinterpret_cast<const uint4*>(wb_ + woff[2]);                                                    \
-    rw3 = *reinterpret_cast<const uint4*>(wb_ + woff[3]);                                                    \
-    ra0 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[0] : aoff0[0]));                              \
-    ra1 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[1] : aoff0[1]));                              \
-    ra2 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[2] : aoff0[2]));                              \
-    ra3 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[3] : aoff0[3]));                              \
-  }
-#define SDG_STORE_SLAB(BUF)                                                   \
-  {                                                                             \
-    char* dw_ = smem + (BUF) * kPStage + lrow * kPRow + lc8 * 16;               \
-    *reinterpret_cast<uint4*>(dw_) = rw0;                                       \
-    *reinterpret_cast<uint4*>(dw_ + 32 * kPRow) = rw1;                          \
-    *reinterpret_cast<uint4*>(dw_ + 64 * kPRow) = rw2;                          \
-    *reinterpret_cast<uint4*>(dw_ + 96 * kPRow) = rw3;                          \
-    *reinterpret_cast<uint4*>(dw_ + 128 * kPRow) = ra0;                         \
-    *reinterpret_cast<uint4*>(dw_ + 160 * kPRow) = ra1;                         \
-    *reinterpret_cast<uint4*>(dw_ + 192 * kPRow) = ra2;                         \
-    *reinterpret_cast<uint4*>(dw_ + 224 * kPRow) = ra3;                         \
-  }
-
-  // this lane's two rays (column tiles tn = 0, 1) and the shifts of all their input blocks (<= 6: fetched once, not inside the loop)
-  constexpr int kMaxGroups = 6;
-  int shg[2][kMaxGroups];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int64_t cray = min(ray0 + wn * 64 + tn * 32 + (lane & 31), A.m - 1);
-#pragma unroll
-    for (int g = 0; g < kMaxGroups; ++g)
-      shg[tn][g] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
-  }
-
-  SDG_LOAD_SLAB(0)
-  const int frow = lane & 31, fk = (lane >> 5) * 16;
-  for (unsigned blk = 0; blk < n_blocks; ++blk) {
-  const int f0 = (int)blk * 128;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  SDG_STORE_SLAB(0)                    // slab 0 of this block: loaded before the loop / during the previous block's last slab
-  __syncthreads();
-  for (int s = 0; s < ks; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < ks) {
-      SDG_LOAD_SLAB(s + 1)
-    } else {                           // the staging registers carry slab 0 of the NEXT block through this block's epilogue
-      wbase = A.wp + ((int64_t)(blk + 1 < n_blocks ? f0 + 128 : f0) * ks) * kSlabB;
-      SDG_LOAD_SLAB(0)
-    }
-    if ((s & 3) == 0 && s > 0) {       // a new block of 128 input features: bring the accumulators to its scale (exact)
-      const int g = s >> 2;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        int d = 0;
-#pragma unroll
-        for (int gg = 1; gg < kMaxGroups; ++gg) d = gg == g ? shg[tn][gg] - shg[tn][gg - 1] : d;     // selects, no dynamic register indexing
-        const float fac = pow2i(d);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;
-      }
-    }
-    const char* sw = smem + buf * kPStage + (wm * 64 + frow) * kPRow + fk;
-    const char* sr = smem + buf * kPStage + (128 + wn * 64 + frow) * kPRow + fk;
-#pragma unroll
-    for (int kstep = 0; kstep < 2; ++kstep) {
-      f16x8_t a[2][2], b[2][2];      // [row block][plane]
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          a[t][p] = *reinterpret_cast<const f16x8_t*>(sw + t * 32 * kPRow + p * 64 + kstep * 32);
-          b[t][p] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + p * 64 + kstep * 32);
-        }
-      constexpr int PA[3] = {1, 0, 0};   // (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first
-      constexpr int PB[3] = {0, 1, 0};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][PA[q]], b[0][PB[q]], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][PA[q]], b[1][PB[q]], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][PA[q]], b[0][PB[q]], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][PA[q]], b[1][PB[q]], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (s + 1 < ks) SDG_STORE_SLAB(buf ^ 1)
-    __syncthreads();
-  }
-#undef SDG_LOAD_SLAB
-#undef SDG_STORE_SLAB
-
+constexpr int kMaxGroups = 6;
+// bias, ReLU, per-(ray, block) scale, split, staging, coalesced stores of one 128-feature block of one 128-ray tile
+__device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, float (*wmaxs)[128], const f32x16 (&acc)[2][2], const int (&shg)[2][kMaxGroups],
+                                               int f0, int64_t ray0, int ks, int lane, int tid, int wm, int wn) {
   // ---- epilogue.  Lane: rays (tn) x features f0 + wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
   float v[2][2][16];
   float rmax[2] = {0.f, 0.f};
@@ -236,50 +109,202 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
       if (ray0 + ray < A.m) *reinterpret_cast<float4*>(A.out_f32 + (ray0 + ray) * A.ldo + f0 + c * 4) = reinterpret_cast<const float4*>(st + ray * (kStRow / 4))[c];
     }
   } else {
-  // per-ray maximum of this block: the partner lane l ^ 32 holds the other features of the same ray, the other feature wave the rest
+    // per-ray maximum of this block: the partner lane l ^ 32 holds the other features of the same ray, the other feature wave the rest
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) rmax[tn] = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
-  if (lane < 32) {
-    wmaxs[wm][wn * 64 + lane] = rmax[0];
-    wmaxs[wm][wn * 64 + 32 + lane] = rmax[1];
+    for (int tn = 0; tn < 2; ++tn) rmax[tn] = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
+    if (lane < 32) {
+      wmaxs[wm][wn * 64 + lane] = rmax[0];
+      wmaxs[wm][wn * 64 + 32 + lane] = rmax[1];
+    }
+    __syncthreads();
+    char* stp = smem;       // staging [ray 128][slab 4][plane 2][32 fp16] = 512 B (+ 16 B pad) per ray
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int ray = wn * 64 + tn * 32 + (lane & 31);
+      const int sh = p_shift(fmaxf(wmaxs[0][ray], wmaxs[1][ray]));
+      const float sc = pow2i(sh);
+      if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * (A.n >> 7) + (f0 >> 7)] = sh;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          f16x4 h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = v[tn][tm][4 * rg + j] * sc;
+            const _Float16 hh = (_Float16)x;
+            h[j] = hh;
+            l[j] = (_Float16)(x - (float)hh);
+          }
+          const int fl = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);     // feature within the block: slab fl >> 5, position fl & 31
+          char* d = stp + ray * kStRow + (fl >> 5) * kSlabB + (fl & 31) * 2;
+          *reinterpret_cast<f16x4*>(d) = h;
+          *reinterpret_cast<f16x4*>(d + 64) = l;
+        }
+    }
+    __syncthreads();
+    const int nslab_out = A.n >> 5;
+    for (int i = tid; i < 128 * 32; i += 256) {
+      const int ray = i >> 5, c = i & 31;
+      if (ray0 + ray < A.m)
+        *reinterpret_cast<uint4*>(A.out_planes + ((ray0 + ray) * nslab_out + (f0 >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stp + ray * kStRow)[c];
+    }
   }
-  __syncthreads();
-  char* stp = smem;       // staging [ray 128][slab 4][plane 2][32 fp16] = 512 B (+ 16 B pad) per ray
+}
+
+// One workgroup = one tile of 128 rays, ALL feature blocks of the layer one after the other (the per-workgroup set-up is paid once per
+// ray tile).  Operand slabs are fetched TWO slabs ahead into two sets of staging registers: with one slab of look-ahead a load had to
+// come back within the 24 MFMAs (0.4 us) of the slab in front of it, which L2 does not do -- the counters showed the matrix pipe busy
+// 32 % of the cycles at an un-throttled 2.1 GHz, i.e. a latency-bound kernel.  The look-ahead runs across feature blocks, so a block's
+// first slabs arrive during the previous block's epilogue.
+__global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n_blocks, unsigned total_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kPStage];      // 73 728 B: two slab stages; the epilogue staging aliases them
+  __shared__ float wmaxs[2][128];                                      // per-ray maxima of the two feature waves
+  const unsigned w = xcd_remap(blockIdx.x, total_tiles);
+  const int64_t ray0 = (int64_t)w * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;               // wm: feature half (MFMA rows), wn: ray half (MFMA columns)
+  const int ks = A.ks0 + A.ks1;
+  f32x16 acc[2][2];
+
+  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab) -- every wave instruction reads 8 FULL cache lines (a lane reading 64
+  // contiguous bytes of its own row touches 32 lines per instruction); 4 instructions x 32 rows per operand.  Row offsets are 32-bit
+  // (a chunk's planes stay below 4 GB) against uniform bases; the loads are unconditional (past the end the last slab is re-read):
+  // with a conditional load hipcc kept the staging registers in scratch and waited for every load right behind its issue.
+  const int lrow = tid >> 3, lc8 = tid & 7;
+  unsigned woff[4], aoff0[4], aoff1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lray = (unsigned)min((int64_t)(i * 32 + lrow), A.m - 1 - ray0);        // ray within the tile, clamped to the last valid one
+    woff[i] = (unsigned)((i * 32 + lrow) * ks) * kSlabB + lc8 * 16;
+    aoff0[i] = (lray * (unsigned)A.ks0) * kSlabB + lc8 * 16;
+    aoff1[i] = (lray * (unsigned)A.ks1) * kSlabB + lc8 * 16;
+  }
+  const char* abase0 = A.a0 + (ray0 * A.ks0) * kSlabB;
+  const char* abase1 = A.a1 ? A.a1 + (ray0 * A.ks1) * kSlabB : abase0;
+  unsigned lb = 0;      // load cursor: feature block and slab of the next fetch
+  int ls = 0;
+  uint4 p0, p1, p2, p3, p4, p5, p6, p7;      // slab t + 1 (weights 0..3, rays 4..7)
+  uint4 q0, q1, q2, q3, q4, q5, q6, q7;      // slab t + 2
+#define SDG_FETCH(R0, R1, R2, R3, R4, R5, R6, R7)                                                            \
+  {                                                                                                          \
+    const bool seg1_ = ls >= A.ks0;                                                                          \
+    const char* wb_ = A.wp + ((int64_t)lb * 128 * ks + ls) * kSlabB;                                         \
+    const char* ab_ = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * kSlabB : abase0 + (unsigned)ls * kSlabB;     \
+    R0 = *reinterpret_cast<const uint4*>(wb_ + woff[0]);                                                     \
+    R1 = *reinterpret_cast<const uint4*>(wb_ + woff[1]);                                                     \
+    R2 = *reinterpret_cast<const uint4*>(wb_ + woff[2]);                                                     \
+    R3 = *reinterpret_cast<const uint4*>(wb_ + woff[3]);                                                     \
+    R4 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[0] : aoff0[0]));                               \
+    R5 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[1] : aoff0[1]));                               \
+    R6 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[2] : aoff0[2]));                               \
+    R7 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[3] : aoff0[3]));                               \
+    if (++ls == ks) {                                                                                        \
+      ls = 0;                                                                                                \
+      lb = lb + 1 < n_blocks ? lb + 1 : lb;                                                                  \
+    }                                                                                                        \
+  }
+#define SDG_STAGE(BUF, R0, R1, R2, R3, R4, R5, R6, R7)                         \
+  {                                                                             \
+    char* dw_ = smem + (BUF) * kPStage + lrow * kPRow + lc8 * 16;               \
+    *reinterpret_cast<uint4*>(dw_) = R0;                                        \
+    *reinterpret_cast<uint4*>(dw_ + 32 * kPRow) = R1;                           \
+    *reinterpret_cast<uint4*>(dw_ + 64 * kPRow) = R2;                           \
+    *reinterpret_cast<uint4*>(dw_ + 96 * kPRow) = R3;                           \
+    *reinterpret_cast<uint4*>(dw_ + 128 * kPRow) = R4;                          \
+    *reinterpret_cast<uint4*>(dw_ + 160 * kPRow) = R5;                          \
+    *reinterpret_cast<uint4*>(dw_ + 192 * kPRow) = R6;                          \
+    *reinterpret_cast<uint4*>(dw_ + 224 * kPRow) = R7;                          \
+  }
+// the set holding slab t + 1 goes to the idle stage and takes slab t + 3; the two sets swap roles (par), no register is copied (a copy
+// p = q would have to wait for q's loads: the look-ahead would be gone)
+// One half of the two-fold unrolled slab loop: rescale if a new input block starts, the slab's 24 MFMAs, the block's epilogue when it was the
+// block's last slab; then the set holding slab t + 1 (R...) goes to the other stage and takes slab t + 3.  The loop alternates HALF(p...)
+// and HALF(q...) in straight-line code, so that the waits in front of the staging stores are counted (vmcnt(8): the other set's loads
+// stay in flight); with a run-time choice of the set the compiler's counter analysis merges both orders and drains the queue.
+#define SDG_HALF(R0, R1, R2, R3, R4, R5, R6, R7)                                                                       \
+  {                                                                                                                     \
+    if ((s & 3) == 0 && s > 0) {                                                                                        \
+      const int g = s >> 2;                                                                                             \
+      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                                \
+        int d = 0;                                                                                                      \
+        _Pragma("unroll") for (int gg = 1; gg < kMaxGroups; ++gg) d = gg == g ? shg[tn][gg] - shg[tn][gg - 1] : d;      \
+        const float fac = pow2i(d);                                                                                     \
+        _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                                \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;                                         \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    const char* sw = smem + buf * kPStage + (wm * 64 + frow) * kPRow + fk;                                              \
+    const char* sr = smem + buf * kPStage + (128 + wn * 64 + frow) * kPRow + fk;                                        \
+    _Pragma("unroll") for (int kstep = 0; kstep < 2; ++kstep) {                                                         \
+      f16x8_t a[2][2], b[2][2];                                                                                         \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                     \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                              \
+          a[t][pl] = *reinterpret_cast<const f16x8_t*>(sw + t * 32 * kPRow + pl * 64 + kstep * 32);                     \
+          b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + kstep * 32);                     \
+        }                                                                                                               \
+      /* (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first */                                        \
+      _Pragma("unroll") for (int qq = 0; qq < 3; ++qq) {                                                                \
+        const int pa = qq == 0 ? 1 : 0, pb = qq == 1 ? 1 : 0;                                                           \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][pa], b[0][pb], acc[0][0], 0, 0, 0);                     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][pa], b[1][pb], acc[0][1], 0, 0, 0);                     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][pa], b[0][pb], acc[1][0], 0, 0, 0);                     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][pa], b[1][pb], acc[1][1], 0, 0, 0);                     \
+      }                                                                                                                 \
+    }                                                                                                                   \
+    int nbuf = buf ^ 1;                                                                                                 \
+    if (s + 1 == ks) {     /* the block is complete: its epilogue borrows both stages */                                \
+      __syncthreads();                                                                                                  \
+      dense_epilogue(A, smem, wmaxs, acc, shg, (int)blk * 128, ray0, ks, lane, tid, wm, wn);                            \
+      __syncthreads();                                                                                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                  \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
+          _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;                                      \
+      s = -1;                                                                                                           \
+      ++blk;                                                                                                            \
+      nbuf = 0;                                                                                                         \
+    }                                                                                                                   \
+    SDG_STAGE(nbuf, R0, R1, R2, R3, R4, R5, R6, R7)                                                                     \
+    SDG_FETCH(R0, R1, R2, R3, R4, R5, R6, R7)                                                                           \
+    __syncthreads();                                                                                                    \
+    buf = nbuf;                                                                                                         \
+    ++s;                                                                                                                \
+  }
+
+  // this lane's two rays (column tiles tn = 0, 1) and the shifts of all their input blocks (<= 6: fetched once, not inside the loop)
+  int shg[2][kMaxGroups];
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
-    const int ray = wn * 64 + tn * 32 + (lane & 31);
-    const int sh = p_shift(fmaxf(wmaxs[0][ray], wmaxs[1][ray]));
-    const float sc = pow2i(sh);
-    if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * (A.n >> 7) + (f0 >> 7)] = sh;
+    const int64_t cray = min(ray0 + wn * 64 + tn * 32 + (lane & 31), A.m - 1);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        f16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float x = v[tn][tm][4 * rg + j] * sc;
-          const _Float16 hh = (_Float16)x;
-          h[j] = hh;
-          l[j] = (_Float16)(x - (float)hh);
-        }
-        const int fl = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);     // feature within the block: slab fl >> 5, position fl & 31
-        char* d = stp + ray * kStRow + (fl >> 5) * kSlabB + (fl & 31) * 2;
-        *reinterpret_cast<f16x4*>(d) = h;
-        *reinterpret_cast<f16x4*>(d + 64) = l;
-      }
+    for (int g = 0; g < kMaxGroups; ++g)
+      shg[tn][g] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
   }
+
+  SDG_FETCH(p0, p1, p2, p3, p4, p5, p6, p7)        // slab 0
+  SDG_STAGE(0, p0, p1, p2, p3, p4, p5, p6, p7)
+  SDG_FETCH(p0, p1, p2, p3, p4, p5, p6, p7)        // slab 1
+  SDG_FETCH(q0, q1, q2, q3, q4, q5, q6, q7)        // slab 2
   __syncthreads();
-  const int nslab_out = A.n >> 5;
-  for (int i = tid; i < 128 * 32; i += 256) {
-    const int ray = i >> 5, c = i & 31;
-    if (ray0 + ray < A.m)
-      *reinterpret_cast<uint4*>(A.out_planes + ((ray0 + ray) * nslab_out + (f0 >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stp + ray * kStRow)[c];
+  const int frow = lane & 31, fk = (lane >> 5) * 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int buf = 0, s = 0;
+  unsigned blk = 0;
+  while (true) {                     // flattened over (feature block, slab); after the very last slab one surplus stage / fetch happens (harmless)
+    SDG_HALF(p0, p1, p2, p3, p4, p5, p6, p7)
+    if (blk >= n_blocks) break;
+    SDG_HALF(q0, q1, q2, q3, q4, q5, q6, q7)
+    if (blk >= n_blocks) break;
   }
-  }                       // planes / fp32 output
-  __syncthreads();        // the staging tile is free again: the next block stores its first slab there
-  }                       // feature blocks
+#undef SDG_HALF
+#undef SDG_FETCH
+#undef SDG_STAGE
 }
 
 // a12 as planes: x[R][5 slabs][2 planes][32] (141 inputs, zero padded to 160), one shift per ray from the bound max(1, |coordinates|)
