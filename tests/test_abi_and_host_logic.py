@@ -193,3 +193,25 @@ def test_bench_plain_multi_gpu_start_becomes_the_launcher():
         pytest.skip("GPU present: covered by tests/test_gpu_bench_contract.py")
     assert p.returncode != 0
     assert "needs an MI355X" in p.stderr and "WORLD_SIZE=1" not in p.stderr, p.stderr[-1500:]
+
+
+def test_select_sample_indices_and_batched_tokens_host_logic():
+    """Host-side pieces of the select path and of the fused q_proj that need no GPU: the ray sample (one ray per group of 16 / 32,
+    strictly increasing, position inside the group varying from group to group) and the BatchedTokens view."""
+    ops = importlib.import_module("6dgs_amd.ops")
+    bb = importlib.import_module("6dgs_amd.backbone")
+    for r, stride in ((1_000_003, 16), (16_000_000, 32), (40, 16)):
+        idx = ops.select_sample_indices(r, "cpu")
+        assert idx.shape[0] == r // stride and idx.dtype == torch.int64
+        if idx.numel():
+            assert bool((idx[1:] > idx[:-1]).all()) and int(idx.max()) < r
+            assert torch.equal(idx // stride, torch.arange(idx.shape[0]))                    # exactly one ray of every group
+            if idx.numel() > 1000:
+                assert len(set((idx % stride).tolist())) == stride                          # every position inside a group is used
+                assert bool(((idx % 64)[:4096].reshape(-1, 4).float().std(dim=1) > 0).any())   # not the same iso-cell direction of every ellipsoid
+    f, pe = torch.randn(3, 256, 384), torch.randn(256, 14)
+    t = bb.BatchedTokens(f, pe)
+    assert t.shape == (3, 256, 398) and len(t) == 3 and t.dense().shape == (3, 256, 398)
+    assert torch.equal(t[1], torch.cat([f[1], pe], dim=-1)) and torch.equal(t.dense()[2], t[2])
+    sub = t[torch.tensor([2, 0])]
+    assert isinstance(sub, bb.BatchedTokens) and torch.equal(sub.feats, f[[2, 0]]) and [x.shape for x in t] == [(256, 398)] * 3
