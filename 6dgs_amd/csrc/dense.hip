@@ -59,8 +59,8 @@ struct DenseArgs {
 
 constexpr int kMaxGroups = 6;
 // bias, ReLU, per-(ray, block) scale, split, staging, coalesced stores of one 128-feature block of one 128-ray tile
-__device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, float (*wmaxs)[128], const f32x16 (&acc)[2][2], const int (&shg)[2][kMaxGroups],
-                                               int f0, int64_t ray0, int ks, int lane, int tid, int wm, int wn) {
+__device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, float (*wmaxs)[128], const float* cwb, const f32x16 (&acc)[2][2],
+                                               const int (&shg)[2][kMaxGroups], int f0, int64_t ray0, int ks, int lane, int tid, int wm, int wn) {
   // ---- epilogue.  Lane: rays (tn) x features f0 + wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
   float v[2][2][16];
   float rmax[2] = {0.f, 0.f};
@@ -77,9 +77,11 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, f
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const int fb = f0 + wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);                 // 4 consecutive features: 16-byte loads of their constants
-      const float4 wm4 = *reinterpret_cast<const float4*>(A.wmax + fb), b4 = *reinterpret_cast<const float4*>(A.bias + fb);
-      const float iw[4] = {f3_inv_scale(wm4.x), f3_inv_scale(wm4.y), f3_inv_scale(wm4.z), f3_inv_scale(wm4.w)};
+      // 4 consecutive features: their constants (reciprocal weight-row scale, bias) from the block's LDS copy.  Read from global memory
+      // here, the 16 loads were waited for two at a time behind their issue: ~4 us of exposed L2 latency per block.
+      const int fl4 = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
+      const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + 128 + fl4);
+      const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -161,6 +163,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, f
 __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n_blocks, unsigned total_tiles) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kPStage];      // 73 728 B: two slab stages; the epilogue staging aliases them
   __shared__ float wmaxs[2][128];                                      // per-ray maxima of the two feature waves
+  __shared__ __attribute__((aligned(16))) float cwb[256];              // the current block's reciprocal weight-row scales [128] and biases [128]
   const unsigned w = xcd_remap(blockIdx.x, total_tiles);
   const int64_t ray0 = (int64_t)w * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
 // stay in flight); with a run-time choice of the set the compiler's counter analysis merges both orders and drains the queue.
 #define SDG_HALF(R0, R1, R2, R3, R4, R5, R6, R7)                                                                       \
   {                                                                                                                     \
+    if (s == 0) creg = tid < 128 ? A.wmax[blk * 128 + tid] : A.bias[blk * 128 + tid - 128];   /* in flight for the whole block */ \
     if ((s & 3) == 0 && s > 0) {                                                                                        \
       const int g = s >> 2;                                                                                             \
       _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                                \
@@ -255,8 +259,9 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
     }                                                                                                                   \
     int nbuf = buf ^ 1;                                                                                                 \
     if (s + 1 == ks) {     /* the block is complete: its epilogue borrows both stages */                                \
+      cwb[tid] = tid < 128 ? f3_inv_scale(creg) : creg;                                                                 \
       __syncthreads();                                                                                                  \
-      dense_epilogue(A, smem, wmaxs, acc, shg, (int)blk * 128, ray0, ks, lane, tid, wm, wn);                            \
+      dense_epilogue(A, smem, wmaxs, cwb, acc, shg, (int)blk * 128, ray0, ks, lane, tid, wm, wn);                       \
       __syncthreads();                                                                                                  \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                  \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
@@ -296,6 +301,7 @@ __global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   int buf = 0, s = 0;
   unsigned blk = 0;
+  float creg = 0.f;
   while (true) {                     // flattened over (feature block, slab); after the very last slab one surplus stage / fetch happens (harmless)
     SDG_HALF(p0, p1, p2, p3, p4, p5, p6, p7)
     if (blk >= n_blocks) break;
