@@ -16,6 +16,7 @@ SOURCES = ["geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip"]
 HEADERS = ["common.h", "device_math.h", "gemm_kernel.h", "dense.h", os.path.join("..", "..", "include", "sixdgs.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("SIXDGS_EXTRA_FLAGS", "").split()       # developer builds (e.g. -DSDG_DENSE_PROF: tools/prof_dense.py)
 
 
 def _stale(target, deps):

@@ -29,7 +29,6 @@ namespace {
 
 constexpr int kSlabB = 128;           // bytes of one (row, slab): plane h 64 B, plane l 64 B
 constexpr int kPRow = 144;            // LDS row stride of a staged slab
-constexpr int kPStage = 256 * kPRow;  // 128 weight rows + 128 ray rows
 constexpr int kStRow = 528;           // staging row of the epilogue: 512 B of a ray + 16 B (with 512 the 32 lanes of a write hit one bank: 32-way conflict)
 constexpr int kShMax = 40;            // activation shifts are clamped to +-40: the rescale between blocks stays far from overflow
 
@@ -58,259 +57,356 @@ struct DenseArgs {
 };
 
 constexpr int kMaxGroups = 6;
-// bias, ReLU, per-(ray, block) scale, split, staging, coalesced stores of one 128-feature block of one 128-ray tile
-__device__ __forceinline__ void dense_epilogue(const DenseArgs& A, char* smem, float (*wmaxs)[128], const float* cwb, const f32x16 (&acc)[2][2],
-                                               const int (&shg)[2][kMaxGroups], int f0, int64_t ray0, int ks, int lane, int tid, int wm, int wn) {
-  // ---- epilogue.  Lane: rays (tn) x features f0 + wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
-  float v[2][2][16];
-  float rmax[2] = {0.f, 0.f};
-  const int glast = (ks - 1) >> 2;
-  float ib[2];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    int shl = 0;
-#pragma unroll
-    for (int gg = 0; gg < kMaxGroups; ++gg) shl = gg == glast ? shg[tn][gg] : shl;
-    ib[tn] = pow2i(-shl);
-  }
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      // 4 consecutive features: their constants (reciprocal weight-row scale, bias) from the block's LDS copy.  Read from global memory
-      // here, the 16 loads were waited for two at a time behind their issue: ~4 us of exposed L2 latency per block.
-      const int fl4 = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
-      const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + 128 + fl4);
-      const float iw[4] = {iw4.x, iw4.y, iw4.z, iw4.w};
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          float x = acc[tm][tn][4 * rg + j] * (iw[j] * ib[tn]) + bb[j];
-          if (A.relu) x = fmaxf(x, 0.f);
-          v[tn][tm][4 * rg + j] = x;
-          rmax[tn] = fmaxf(rmax[tn], fabsf(x));
-        }
-    }
-  if (A.out_f32 != nullptr) {
-    // fp32 rows through the staging tile [ray][128 features + pad] (66 KiB), then 16-byte pieces: 512 contiguous bytes per ray
-    float* st = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int ray = wn * 64 + tn * 32 + (lane & 31), fl = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
-          *reinterpret_cast<float4*>(st + ray * (kStRow / 4) + fl) = float4{v[tn][tm][4 * rg], v[tn][tm][4 * rg + 1], v[tn][tm][4 * rg + 2], v[tn][tm][4 * rg + 3]};
-        }
-    __syncthreads();
-    for (int i = tid; i < 128 * 32; i += 256) {
-      const int ray = i >> 5, c = i & 31;
-      if (ray0 + ray < A.m) *reinterpret_cast<float4*>(A.out_f32 + (ray0 + ray) * A.ldo + f0 + c * 4) = reinterpret_cast<const float4*>(st + ray * (kStRow / 4))[c];
-    }
-  } else {
-    // per-ray maximum of this block: the partner lane l ^ 32 holds the other features of the same ray, the other feature wave the rest
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) rmax[tn] = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
-    if (lane < 32) {
-      wmaxs[wm][wn * 64 + lane] = rmax[0];
-      wmaxs[wm][wn * 64 + 32 + lane] = rmax[1];
-    }
-    __syncthreads();
-    char* stp = smem;       // staging [ray 128][slab 4][plane 2][32 fp16] = 512 B (+ 16 B pad) per ray
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int ray = wn * 64 + tn * 32 + (lane & 31);
-      const int sh = p_shift(fmaxf(wmaxs[0][ray], wmaxs[1][ray]));
-      const float sc = pow2i(sh);
-      if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * (A.n >> 7) + (f0 >> 7)] = sh;
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-          f16x4 h, l;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float x = v[tn][tm][4 * rg + j] * sc;
-            const _Float16 hh = (_Float16)x;
-            h[j] = hh;
-            l[j] = (_Float16)(x - (float)hh);
-          }
-          const int fl = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);     // feature within the block: slab fl >> 5, position fl & 31
-          char* d = stp + ray * kStRow + (fl >> 5) * kSlabB + (fl & 31) * 2;
-          *reinterpret_cast<f16x4*>(d) = h;
-          *reinterpret_cast<f16x4*>(d + 64) = l;
-        }
-    }
-    __syncthreads();
-    const int nslab_out = A.n >> 5;
-    for (int i = tid; i < 128 * 32; i += 256) {
-      const int ray = i >> 5, c = i & 31;
-      if (ray0 + ray < A.m)
-        *reinterpret_cast<uint4*>(A.out_planes + ((ray0 + ray) * nslab_out + (f0 >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stp + ray * kStRow)[c];
-    }
-  }
-}
+#ifdef SDG_DENSE_PROF      // developer build (SIXDGS_EXTRA_FLAGS=-DSDG_DENSE_PROF): cycle stamps of one workgroup's loop sections
+__device__ long long g_dense_prof[8 * 16];
+#define SDG_T(V) const long long V = clock64();
+#define SDG_ACC(K, A_, B_) prof_t[K] += (B_) - (A_);
+#else
+#define SDG_T(V)
+#define SDG_ACC(K, A_, B_)
+#endif
+constexpr int kWRows = 512;                    // rows of a staged slab: 256 weight rows (one pass of features) + 256 ray rows
+constexpr int kWStage = kWRows * kPRow;        // 73 728 B
 
-// One workgroup = one tile of 128 rays, ALL feature blocks of the layer one after the other (the per-workgroup set-up is paid once per
-// ray tile).  Operand slabs are fetched TWO slabs ahead into two sets of staging registers: with one slab of look-ahead a load had to
-// come back within the 24 MFMAs (0.4 us) of the slab in front of it, which L2 does not do -- the counters showed the matrix pipe busy
-// 32 % of the cycles at an un-throttled 2.1 GHz, i.e. a latency-bound kernel.  The look-ahead runs across feature blocks, so a block's
-// first slabs arrive during the previous block's epilogue.
-__global__ void __launch_bounds__(256, 2) k_dense_planes(DenseArgs A, unsigned n_blocks, unsigned total_tiles) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kPStage];      // 73 728 B: two slab stages; the epilogue staging aliases them
-  __shared__ float wmaxs[2][128];                                      // per-ray maxima of the two feature waves
-  __shared__ __attribute__((aligned(16))) float cwb[256];              // the current block's reciprocal weight-row scales [128] and biases [128]
+// One workgroup (8 waves) = one tile of 256 rays; the layer's features in passes of 256 (wave = 64 features x 128 rays: 2 x 4 MFMA tiles,
+// 24 MFMAs per 12 LDS fragment reads -- the 128 x 128 / 4-wave tiling this replaces read 1 KB of LDS per MFMA and was bound by that; this
+// is the logits kernel's 0.4 KB per MFMA).  Operand slabs go global -> registers -> LDS one slab ahead (a slab is 48 MFMAs per wave, 1.5 us:
+// L2 answers within that); the look-ahead runs across passes, so a pass's first slab arrives during the previous pass's epilogue.
+// Epilogue per pass: bias, ReLU, per-(ray, 128-feature block) power-of-two scale, fp16 split, LDS staging, coalesced 16-byte stores.
+__global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n_pass, unsigned total_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kWStage];      // two slab stages; the epilogue staging [256 rays][528 B] aliases them
+  __shared__ float wmaxs[4][256];                                      // per-ray maxima of the four feature waves
+  __shared__ __attribute__((aligned(16))) float cwb[512];              // the pass's reciprocal weight-row scales [256] and biases [256]
+  __shared__ int shl[kMaxGroups][256];                                 // input shifts of the tile's rays, per 128-input block
   const unsigned w = xcd_remap(blockIdx.x, total_tiles);
-  const int64_t ray0 = (int64_t)w * 128;
+  const int64_t ray0 = (int64_t)w * 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;               // wm: feature half (MFMA rows), wn: ray half (MFMA columns)
+  const int wm = wave >> 1, wn = wave & 1;               // wm: 64 features of the pass (MFMA rows), wn: 128 rays (MFMA columns)
   const int ks = A.ks0 + A.ks1;
-  f32x16 acc[2][2];
+  const int nb_all = A.n >> 7;
+  f32x16 acc[2][4];
 
-  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab) -- every wave instruction reads 8 FULL cache lines (a lane reading 64
-  // contiguous bytes of its own row touches 32 lines per instruction); 4 instructions x 32 rows per operand.  Row offsets are 32-bit
-  // (a chunk's planes stay below 4 GB) against uniform bases; the loads are unconditional (past the end the last slab is re-read):
-  // with a conditional load hipcc kept the staging registers in scratch and waited for every load right behind its issue.
-  const int lrow = tid >> 3, lc8 = tid & 7;
-  unsigned woff[4], aoff0[4], aoff1[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lray = (unsigned)min((int64_t)(i * 32 + lrow), A.m - 1 - ray0);        // ray within the tile, clamped to the last valid one
-    woff[i] = (unsigned)((i * 32 + lrow) * ks) * kSlabB + lc8 * 16;
-    aoff0[i] = (lray * (unsigned)A.ks0) * kSlabB + lc8 * 16;
-    aoff1[i] = (lray * (unsigned)A.ks1) * kSlabB + lc8 * 16;
+  for (int i = tid; i < kMaxGroups * 256; i += 512) {
+    const int g = i >> 8;
+    const int64_t cray = min(ray0 + (i & 255), A.m - 1);
+    shl[g][i & 255] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
   }
+
+  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 4 instructions x 64
+  // rows per operand.  Addresses are a uniform base (advanced per slab on the scalar unit) + a 32-bit per-thread offset that only changes
+  // with the pass (weights) or the input segment (rays).  Loads are unconditional with clamped rows.
+  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16;
   const char* abase0 = A.a0 + (ray0 * A.ks0) * kSlabB;
   const char* abase1 = A.a1 ? A.a1 + (ray0 * A.ks1) * kSlabB : abase0;
-  unsigned lb = 0;      // load cursor: feature block and slab of the next fetch
+  const unsigned rmax = (unsigned)min((int64_t)255, A.m - 1 - ray0);      // last valid ray of the tile
+  unsigned lb = 0;      // load cursor: pass and slab of the next fetch
   int ls = 0;
-  uint4 p0, p1, p2, p3, p4, p5, p6, p7;      // slab t + 1 (weights 0..3, rays 4..7)
-  uint4 q0, q1, q2, q3, q4, q5, q6, q7;      // slab t + 2
-#define SDG_FETCH(R0, R1, R2, R3, R4, R5, R6, R7)                                                            \
-  {                                                                                                          \
-    const bool seg1_ = ls >= A.ks0;                                                                          \
-    const char* wb_ = A.wp + ((int64_t)lb * 128 * ks + ls) * kSlabB;                                         \
-    const char* ab_ = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * kSlabB : abase0 + (unsigned)ls * kSlabB;     \
-    R0 = *reinterpret_cast<const uint4*>(wb_ + woff[0]);                                                     \
-    R1 = *reinterpret_cast<const uint4*>(wb_ + woff[1]);                                                     \
-    R2 = *reinterpret_cast<const uint4*>(wb_ + woff[2]);                                                     \
-    R3 = *reinterpret_cast<const uint4*>(wb_ + woff[3]);                                                     \
-    R4 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[0] : aoff0[0]));                               \
-    R5 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[1] : aoff0[1]));                               \
-    R6 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[2] : aoff0[2]));                               \
-    R7 = *reinterpret_cast<const uint4*>(ab_ + (seg1_ ? aoff1[3] : aoff0[3]));                               \
-    if (++ls == ks) {                                                                                        \
-      ls = 0;                                                                                                \
-      lb = lb + 1 < n_blocks ? lb + 1 : lb;                                                                  \
-    }                                                                                                        \
+  uint4 p0, p1, p2, p3, p4, p5, p6, p7;      // the slab in flight (weights 0..3, rays 4..7); named: an array ended up in scratch
+  // uniform bases and row strides of the cursor's slab; a load's address is base + 32-bit offset, three VALU operations per load
+#define SDG_BASES()                                                                                                       \
+  const char* wbase = A.wp + (unsigned)ls * kSlabB;                                                                       \
+  const bool seg1_ = ls >= A.ks0;                                                                                         \
+  const char* abase = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * kSlabB : abase0 + (unsigned)ls * kSlabB;                  \
+  const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * kSlabB, wstride = (unsigned)ks * kSlabB;                   \
+  const unsigned wrow0 = lb * 256u, wrmax = (unsigned)A.n - 1u;
+#define SDG_LOAD(J, P)                                                                                                    \
+  P = *reinterpret_cast<const uint4*>((J) < 4 ? wbase + (min(wrow0 + 64u * ((J) & 3) + lrow, wrmax) * wstride + lc16)     \
+                                              : abase + (min(64u * ((J) & 3) + lrow, rmax) * astride + lc16));
+#define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
+#define SDG_WRITE(DST, J, P) *reinterpret_cast<uint4*>((DST) + (J) * 64 * kPRow) = P;
+#define SDG_WRITE_ALL(DST) SDG_WRITE(DST, 0, p0) SDG_WRITE(DST, 1, p1) SDG_WRITE(DST, 2, p2) SDG_WRITE(DST, 3, p3) SDG_WRITE(DST, 4, p4) SDG_WRITE(DST, 5, p5) SDG_WRITE(DST, 6, p6) SDG_WRITE(DST, 7, p7)
+#define SDG_ADVANCE()                           \
+  if (++ls == ks) {                             \
+    ls = 0;                                     \
+    lb = lb + 1 < n_pass ? lb + 1 : lb;         \
   }
-#define SDG_STAGE(BUF, R0, R1, R2, R3, R4, R5, R6, R7)                         \
-  {                                                                             \
-    char* dw_ = smem + (BUF) * kPStage + lrow * kPRow + lc8 * 16;               \
-    *reinterpret_cast<uint4*>(dw_) = R0;                                        \
-    *reinterpret_cast<uint4*>(dw_ + 32 * kPRow) = R1;                           \
-    *reinterpret_cast<uint4*>(dw_ + 64 * kPRow) = R2;                           \
-    *reinterpret_cast<uint4*>(dw_ + 96 * kPRow) = R3;                           \
-    *reinterpret_cast<uint4*>(dw_ + 128 * kPRow) = R4;                          \
-    *reinterpret_cast<uint4*>(dw_ + 160 * kPRow) = R5;                          \
-    *reinterpret_cast<uint4*>(dw_ + 192 * kPRow) = R6;                          \
-    *reinterpret_cast<uint4*>(dw_ + 224 * kPRow) = R7;                          \
+  {
+    SDG_BASES()
+    SDG_LOAD_ALL()       // slab 0
+    SDG_ADVANCE()
   }
-// the set holding slab t + 1 goes to the idle stage and takes slab t + 3; the two sets swap roles (par), no register is copied (a copy
-// p = q would have to wait for q's loads: the look-ahead would be gone)
-// One half of the two-fold unrolled slab loop: rescale if a new input block starts, the slab's 24 MFMAs, the block's epilogue when it was the
-// block's last slab; then the set holding slab t + 1 (R...) goes to the other stage and takes slab t + 3.  The loop alternates HALF(p...)
-// and HALF(q...) in straight-line code, so that the waits in front of the staging stores are counted (vmcnt(8): the other set's loads
-// stay in flight); with a run-time choice of the set the compiler's counter analysis merges both orders and drains the queue.
-#define SDG_HALF(R0, R1, R2, R3, R4, R5, R6, R7)                                                                       \
-  {                                                                                                                     \
-    if (s == 0) creg = tid < 128 ? A.wmax[blk * 128 + tid] : A.bias[blk * 128 + tid - 128];   /* in flight for the whole block */ \
-    if ((s & 3) == 0 && s > 0) {                                                                                        \
-      const int g = s >> 2;                                                                                             \
-      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                                                \
-        int d = 0;                                                                                                      \
-        _Pragma("unroll") for (int gg = 1; gg < kMaxGroups; ++gg) d = gg == g ? shg[tn][gg] - shg[tn][gg - 1] : d;      \
-        const float fac = pow2i(d);                                                                                     \
-        _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                                                \
-          _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;                                         \
-      }                                                                                                                 \
-    }                                                                                                                   \
-    const char* sw = smem + buf * kPStage + (wm * 64 + frow) * kPRow + fk;                                              \
-    const char* sr = smem + buf * kPStage + (128 + wn * 64 + frow) * kPRow + fk;                                        \
-    _Pragma("unroll") for (int kstep = 0; kstep < 2; ++kstep) {                                                         \
-      f16x8_t a[2][2], b[2][2];                                                                                         \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                     \
-        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                              \
-          a[t][pl] = *reinterpret_cast<const f16x8_t*>(sw + t * 32 * kPRow + pl * 64 + kstep * 32);                     \
-          b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + kstep * 32);                     \
-        }                                                                                                               \
-      /* (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first */                                        \
-      _Pragma("unroll") for (int qq = 0; qq < 3; ++qq) {                                                                \
-        const int pa = qq == 0 ? 1 : 0, pb = qq == 1 ? 1 : 0;                                                           \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][pa], b[0][pb], acc[0][0], 0, 0, 0);                     \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][pa], b[1][pb], acc[0][1], 0, 0, 0);                     \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][pa], b[0][pb], acc[1][0], 0, 0, 0);                     \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][pa], b[1][pb], acc[1][1], 0, 0, 0);                     \
-      }                                                                                                                 \
-    }                                                                                                                   \
-    int nbuf = buf ^ 1;                                                                                                 \
-    if (s + 1 == ks) {     /* the block is complete: its epilogue borrows both stages */                                \
-      cwb[tid] = tid < 128 ? f3_inv_scale(creg) : creg;                                                                 \
-      __syncthreads();                                                                                                  \
-      dense_epilogue(A, smem, wmaxs, cwb, acc, shg, (int)blk * 128, ray0, ks, lane, tid, wm, wn);                       \
-      __syncthreads();                                                                                                  \
-      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                  \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                \
-          _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;                                      \
-      s = -1;                                                                                                           \
-      ++blk;                                                                                                            \
-      nbuf = 0;                                                                                                         \
-    }                                                                                                                   \
-    SDG_STAGE(nbuf, R0, R1, R2, R3, R4, R5, R6, R7)                                                                     \
-    SDG_FETCH(R0, R1, R2, R3, R4, R5, R6, R7)                                                                           \
-    __syncthreads();                                                                                                    \
-    buf = nbuf;                                                                                                         \
-    ++s;                                                                                                                \
+  {
+    char* const dw0 = smem + lrow * kPRow + lc16;
+    SDG_WRITE_ALL(dw0)
   }
-
-  // this lane's two rays (column tiles tn = 0, 1) and the shifts of all their input blocks (<= 6: fetched once, not inside the loop)
-  int shg[2][kMaxGroups];
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int64_t cray = min(ray0 + wn * 64 + tn * 32 + (lane & 31), A.m - 1);
-#pragma unroll
-    for (int g = 0; g < kMaxGroups; ++g)
-      shg[tn][g] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
+  {
+    SDG_BASES()
+    SDG_LOAD_ALL()       // slab 1
+    SDG_ADVANCE()
   }
-
-  SDG_FETCH(p0, p1, p2, p3, p4, p5, p6, p7)        // slab 0
-  SDG_STAGE(0, p0, p1, p2, p3, p4, p5, p6, p7)
-  SDG_FETCH(p0, p1, p2, p3, p4, p5, p6, p7)        // slab 1
-  SDG_FETCH(q0, q1, q2, q3, q4, q5, q6, q7)        // slab 2
   __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   int buf = 0, s = 0;
-  unsigned blk = 0;
+  unsigned pass = 0;
   float creg = 0.f;
-  while (true) {                     // flattened over (feature block, slab); after the very last slab one surplus stage / fetch happens (harmless)
-    SDG_HALF(p0, p1, p2, p3, p4, p5, p6, p7)
-    if (blk >= n_blocks) break;
-    SDG_HALF(q0, q1, q2, q3, q4, q5, q6, q7)
-    if (blk >= n_blocks) break;
+#ifdef SDG_DENSE_PROF
+  long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long prof_start = clock64();
+  const long long prof_rt = wall_clock64();
+#endif
+  const int rayl = wn * 128 + (lane & 31);        // this lane's rays: rayl + 32 * tn
+// The barrier sits in the MIDDLE of a slab, behind the last slot: every wave passing it has issued all its writes of the next slab and
+// holds the second half's fragments in registers, i.e. has finished reading this slab's stage.  Behind it the next slab's stage is
+// complete and this slab's stage is free for the slab after next: one barrier per slab, at a point where every wave still has 16
+// MFMAs to issue, and a wave runs from a slab's last MFMA straight into the next slab's fragment reads (with the barrier at the slab's
+// end the matrix pipe drained there: 4300 cycles per slab against 3072 of MFMA work).
+// One slab of MFMAs.  SLOTS: after each group of 4 MFMAs one staging register goes to the idle LDS stage (the slab loaded during the
+// previous iteration) and is re-loaded with its piece of the slab after that -- the loads and LDS writes of all waves are spread over the
+// MFMA time instead of arriving together behind it (measured before: 35 % of a slab's cycles in staging, load issue and the barrier
+// with the matrix pipe idle).  A load has one full slab (48 MFMAs per wave, two waves per SIMD: ~2 us) to come back.
+#ifndef SDG_EXP
+#define SDG_EXP 0
+#endif
+#if SDG_EXP == 1 || SDG_EXP == 3       // timing experiments (wrong results): no loads / no LDS writes in the slots
+#define SDG_XLOAD(J, P)
+#else
+#define SDG_XLOAD(J, P) SDG_LOAD(J, P)
+#endif
+#if SDG_EXP == 2 || SDG_EXP == 3
+#define SDG_XWRITE(D, J, P)
+#else
+#define SDG_XWRITE(D, J, P) SDG_WRITE(D, J, P)
+#endif
+#define SDG_SLOT(J, P)                     \
+  {                                        \
+    __builtin_amdgcn_sched_barrier(0);     \
+    SDG_XWRITE(dw, J, P)                   \
+    SDG_XLOAD(J, P)                        \
+    __builtin_amdgcn_sched_barrier(0);     \
   }
-#undef SDG_HALF
-#undef SDG_FETCH
-#undef SDG_STAGE
+#define SDG_FRAGS(KSTEP)                                                                                                                      \
+  _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) a[t][pl] = *reinterpret_cast<const f16x8_t*>(sw + t * 32 * kPRow + pl * 64 + (KSTEP) * 32); \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + (KSTEP) * 32); \
+  }
+// (weight plane PA, ray plane PB) of feature tile TM against the 4 ray tiles
+#define SDG_MFMA4(TM, PA, PB)                                                                                               \
+  _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                                          \
+    acc[TM][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TM][PA], b[tn][PB], acc[TM][tn], 0, 0, 0);
+// plane pairs in the order l*h, h*l, h*h -- smallest magnitude first
+#define SDG_SLAB(SL)                                          \
+  {                                                           \
+    f16x8_t a[2][2], b[4][2];                                 \
+    SDG_FRAGS(0)                                              \
+    SDG_MFMA4(0, 1, 0) SL(0, p0) SDG_MFMA4(1, 1, 0) SL(1, p1) \
+    SDG_MFMA4(0, 0, 1) SL(2, p2) SDG_MFMA4(1, 0, 1) SL(3, p3) \
+    SDG_MFMA4(0, 0, 0) SL(4, p4) SDG_MFMA4(1, 0, 0) SL(5, p5) \
+    SDG_FRAGS(1)                                              \
+    SDG_MFMA4(0, 1, 0) SL(6, p6) SDG_MFMA4(1, 1, 0) SL(7, p7) \
+    __syncthreads(); /* the slab's ONE barrier, see below */  \
+    SDG_MFMA4(0, 0, 1) SDG_MFMA4(1, 0, 1)                     \
+    SDG_MFMA4(0, 0, 0) SDG_MFMA4(1, 0, 0)                     \
+  }
+  while (true) {                     // flattened over (pass, slab)
+    const int nfeat = min(256, A.n - (int)pass * 256);       // features of this pass (128 or 256)
+    const bool active = wm * 64 < nfeat;                     // wave-uniform
+    const bool last = s + 1 == ks;
+    SDG_T(t0_)
+    if (s == 0) {     // in flight for the whole pass
+      const int f = min((int)pass * 256 + (tid & 255), A.n - 1);
+      const float cw_ = A.wmax[f], cb_ = A.bias[f];      // both against uniform bases (a per-lane pointer select lived in VGPRs, spilled)
+      creg = tid < 256 ? cw_ : cb_;
+    }
+    SDG_BASES()
+    char* dw = smem + (buf ^ 1) * kWStage + lrow * kPRow + lc16;
+    if (active) {
+      if ((s & 3) == 0 && s > 0) {       // a new 128-input block: accumulators to its scale (exact powers of two)
+        const int* sp = &shl[0][0] + ((s >> 2) << 8) + rayl;      // one address, constant offsets (separate row / ray indices were hoisted and spilled)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          const float fac = pow2i(sp[32 * tn] - sp[32 * tn - 256]);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;
+        }
+      }
+      const char* sw = smem + buf * kWStage + (wm * 64 + frow) * kPRow + fk;
+      const char* sr = smem + buf * kWStage + (256 + wn * 128 + frow) * kPRow + fk;
+      SDG_SLAB(SDG_SLOT)
+    } else {
+      SDG_WRITE_ALL(dw)
+      SDG_LOAD_ALL()
+      __syncthreads();
+    }
+    SDG_ADVANCE()
+    SDG_T(t1_)
+    SDG_ACC(pass == 0 ? 0 : 6, t0_, t1_)
+    if (last) {     // the pass is complete: its epilogue borrows the stage just consumed (the other one holds the next pass's first slab)
+      char* const stg = smem + buf * kWStage;        // staging [128 rays][528 B]: one (128-feature block, 128-ray half) at a time
+      cwb[tid] = tid < 256 ? f3_inv_scale(creg) : creg;
+      __syncthreads();
+      const int f0 = (int)pass * 256;
+      const int nblk = nfeat >> 7;
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const bool planes_out = A.out_f32 == nullptr;
+      if (active) {
+        // lane: rays rayl + 32 tn, features (of the pass) wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); acc becomes the layer output in place.
+        // All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed fp32
+        // multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value (4.4 before).
+        const int glast = (ks - 1) >> 2;
+        const float relu_floor = A.relu ? 0.f : -__builtin_inff();
+        float rmax[4] = {0.f, 0.f, 0.f, 0.f};
+        float ib[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) ib[tn] = pow2i(-shl[glast][rayl + 32 * tn]);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int fl4 = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
+            const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + 256 + fl4);
+            const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
+            const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+              for (int jp = 0; jp < 2; ++jp) {
+                f32x2_t v = {acc[tm][tn][4 * rg + 2 * jp], acc[tm][tn][4 * rg + 2 * jp + 1]};
+                v = v * f32x2_t{ib[tn], ib[tn]};
+                v = __builtin_elementwise_fma(v, iw[jp], bb[jp]);
+                const float x0 = fmaxf(v.x, relu_floor), x1 = fmaxf(v.y, relu_floor);
+                acc[tm][tn][4 * rg + 2 * jp] = x0;
+                acc[tm][tn][4 * rg + 2 * jp + 1] = x1;
+                rmax[tn] = fmaxf(fmaxf(rmax[tn], fabsf(x0)), fabsf(x1));
+              }
+          }
+        if (planes_out) {
+          // per-ray maximum: the partner lane l ^ 32 holds the other features of the same ray, the block's other feature wave the rest
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) rmax[tn] = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
+          if (lane < 32) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) wmaxs[wm][rayl + 32 * tn] = rmax[tn];
+          }
+        }
+      }
+      __syncthreads();
+      if (active && planes_out) {
+        // every wave splits its values now (in place: 4 values -> 2 registers of h, 2 of l), so that the unit loop below only moves bytes
+        const int bw = wm >> 1;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          const int ray = rayl + 32 * tn;
+          const int sh = p_shift(fmaxf(wmaxs[2 * bw][ray], wmaxs[2 * bw + 1][ray]));
+          const float sc = pow2i(sh);
+          if ((wm & 1) == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + bw] = sh;
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              f16x4 h, l;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float x = acc[tm][tn][4 * rg + j] * sc;
+                const _Float16 hh = (_Float16)x;
+                h[j] = hh;
+                l[j] = (_Float16)(x - (float)hh);
+              }
+              const f32x2_t hb = __builtin_bit_cast(f32x2_t, h), lb2 = __builtin_bit_cast(f32x2_t, l);
+              acc[tm][tn][4 * rg] = hb.x;
+              acc[tm][tn][4 * rg + 1] = hb.y;
+              acc[tm][tn][4 * rg + 2] = lb2.x;
+              acc[tm][tn][4 * rg + 3] = lb2.y;
+            }
+        }
+      }
+      SDG_T(tu0_)
+      SDG_ACC(1, t1_, tu0_)
+      for (int unit = 0; unit < 2 * nblk; ++unit) {         // (128-feature block, 128-ray half): the two waves holding it fill the staging tile
+        const int bsel = unit >> 1, hsel = unit & 1;
+        SDG_T(tu1_)
+        if ((wm >> 1) == bsel && wn == hsel) {
+          const int fw = (wm & 1) * 64;                 // this wave's features within the block
+          if (!planes_out) {
+            float* st = reinterpret_cast<float*>(stg);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                  *reinterpret_cast<float4*>(st + ((lane & 31) + 32 * tn) * (kStRow / 4) + fw + tm * 32 + 8 * rg + 4 * (lane >> 5)) =
+                      float4{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1], acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+              for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                  const int fl = fw + tm * 32 + 8 * rg + 4 * (lane >> 5);     // feature within the block: slab fl >> 5, position fl & 31
+                  char* d = stg + ((lane & 31) + 32 * tn) * kStRow + (fl >> 5) * kSlabB + (fl & 31) * 2;
+                  *reinterpret_cast<f32x2_t*>(d) = f32x2_t{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1]};
+                  *reinterpret_cast<f32x2_t*>(d + 64) = f32x2_t{acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
+                }
+          }
+        }
+        SDG_T(tu2_)
+        SDG_ACC(2, tu1_, tu2_)
+        __syncthreads();
+        SDG_T(tu3_)
+        SDG_ACC(5, tu2_, tu3_)
+        const int fb = f0 + bsel * 128;
+        const int64_t rbase = ray0 + hsel * 128;
+        if (A.out_f32 != nullptr) {
+#pragma unroll
+          for (int i = tid; i < 128 * 32; i += 512) {
+            const int ray = i >> 5, c = i & 31;
+            if (rbase + ray < A.m)
+              *reinterpret_cast<float4*>(A.out_f32 + (rbase + ray) * A.ldo + fb + c * 4) = reinterpret_cast<const float4*>(stg + ray * kStRow)[c];
+          }
+        } else {
+          const int nslab_out = A.n >> 5;
+#pragma unroll
+          for (int i = tid; i < 128 * 32; i += 512) {
+            const int ray = i >> 5, c = i & 31;
+            if (rbase + ray < A.m)
+              *reinterpret_cast<uint4*>(A.out_planes + ((rbase + ray) * nslab_out + (fb >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stg + ray * kStRow)[c];
+          }
+        }
+        SDG_T(tu4_)
+        SDG_ACC(4, tu3_, tu4_)
+        __syncthreads();
+        SDG_T(tu5_)
+        SDG_ACC(7, tu4_, tu5_)
+      }
+      if (++pass >= n_pass) break;
+#pragma unroll
+      for (int i_ = 0; i_ < 2; ++i_)
+#pragma unroll
+        for (int j_ = 0; j_ < 4; ++j_)
+#pragma unroll
+          for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;
+      s = -1;
+    }
+    buf ^= 1;
+    ++s;
+  }
+#undef SDG_SLAB
+#undef SDG_SLOT
+#undef SDG_FRAGS
+#undef SDG_MFMA4
+#undef SDG_LOAD
+#undef SDG_LOAD_ALL
+#undef SDG_WRITE
+#undef SDG_WRITE_ALL
+#undef SDG_BASES
+#undef SDG_ADVANCE
+#ifdef SDG_DENSE_PROF
+  if (blockIdx.x == total_tiles / 2 && lane == 0) {
+    for (int k = 0; k < 8; ++k) g_dense_prof[wave * 16 + k] = prof_t[k];
+    g_dense_prof[wave * 16 + 8] = clock64() - prof_start;
+    g_dense_prof[wave * 16 + 9] = wall_clock64() - prof_rt;      // 100 MHz
+  }
+#endif
 }
 
 // a12 as planes: x[R][5 slabs][2 planes][32] (141 inputs, zero padded to 160), one shift per ray from the bound max(1, |coordinates|)
@@ -366,15 +462,19 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
 }
 
 int launch_dense(const DenseArgs& A, hipStream_t s) {
-  const int64_t m_tiles = sdg_cdiv(A.m, 128);
+  const int64_t m_tiles = sdg_cdiv(A.m, 256);
   if (m_tiles <= 0) return 0;
   if (m_tiles > 0x7fffffffLL) return SIXDGS_E_BADARG;
-  hipLaunchKernelGGL(k_dense_planes, dim3((unsigned)m_tiles), dim3(256), 0, s, A, (unsigned)(A.n / 128), (unsigned)m_tiles);
+  hipLaunchKernelGGL(k_dense_planes, dim3((unsigned)m_tiles), dim3(512), 0, s, A, (unsigned)sdg_cdiv(A.n, 256), (unsigned)m_tiles);
   SDG_LAUNCH_OK();
   return 0;
 }
 
 }  // namespace
+
+#ifdef SDG_DENSE_PROF
+extern "C" int sixdgs_debug_dense_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_prof), sizeof(long long) * 128); }
+#endif
 
 namespace sdg {
 

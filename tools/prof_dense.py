@@ -1,0 +1,23 @@
+"""Developer tool: cycle stamps of k_dense_planes' loop sections (needs a library built with SIXDGS_EXTRA_FLAGS=-DSDG_DENSE_PROF).
+Runs the plane-to-plane chain on one chunk of rays and prints, per wave of one workgroup of the LAST layer launched, the cycles spent
+issuing MFMAs (incl. LDS fragment waits), staging (global-load waits + LDS writes), issuing fetches, in the barrier and in the epilogue."""
+import ctypes, importlib, os, sys
+os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+syn = importlib.import_module("6dgs_amd.synthetic"); ops = importlib.import_module("6dgs_amd.ops"); lib = importlib.import_module("6dgs_amd._lib")
+R = 262144
+rays = syn.make_rays(R, 0)
+o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, "cuda")
+for _ in range(2):
+    ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
+torch.cuda.synchronize()
+h = ctypes.CDLL(lib.LIB_PATH)
+buf = (ctypes.c_longlong * 128)()
+assert h.sixdgs_debug_dense_prof(buf) == 0
+print("wave slabs(pass0) slabs(pass1) | epilogue: transform  stage-write  barrier  copy-out  barrier | total cycles, wall us, GHz   (last layer: 12 slabs x 2 passes, 3 blocks)")
+for wv in range(8):
+    v = buf[wv * 16: wv * 16 + 16]
+    print(f"{wv:4d} {v[0]:9d} {v[6]:9d} | {v[1]:9d} {v[2]:9d} {v[5]:9d} {v[4]:9d} {v[7]:9d} | {v[8]:8d} {v[9] / 100:7.1f} {v[8] / max(v[9], 1) / 10:5.2f}")
