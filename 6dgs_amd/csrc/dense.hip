@@ -57,6 +57,7 @@ struct DenseArgs {
 };
 
 constexpr int kMaxGroups = 6;
+constexpr int kMaxN = 512;                      // widest layer
 #ifdef SDG_DENSE_PROF      // developer build (SIXDGS_EXTRA_FLAGS=-DSDG_DENSE_PROF): cycle stamps of one workgroup's loop sections
 __device__ long long g_dense_prof[8 * 16];
 #define SDG_T(V) const long long V = clock64();
@@ -65,60 +66,106 @@ __device__ long long g_dense_prof[8 * 16];
 #define SDG_T(V)
 #define SDG_ACC(K, A_, B_)
 #endif
-constexpr int kWRows = 512;                    // rows of a staged slab: 256 weight rows (one pass of features) + 256 ray rows
+constexpr int kWRows = 512;                    // rows of a staged slab: the pass's weight rows + the tile's ray rows
 constexpr int kWStage = kWRows * kPRow;        // 73 728 B
 
-// One workgroup (8 waves) = one tile of 256 rays; the layer's features in passes of 256 (wave = 64 features x 128 rays: 2 x 4 MFMA tiles,
-// 24 MFMAs per 12 LDS fragment reads -- the 128 x 128 / 4-wave tiling this replaces read 1 KB of LDS per MFMA and was bound by that; this
-// is the logits kernel's 0.4 KB per MFMA).  Operand slabs go global -> registers -> LDS one slab ahead (a slab is 48 MFMAs per wave, 1.5 us:
-// L2 answers within that); the look-ahead runs across passes, so a pass's first slab arrives during the previous pass's epilogue.
-// Epilogue per pass: bias, ReLU, per-(ray, 128-feature block) power-of-two scale, fp16 split, LDS staging, coalesced 16-byte stores.
+// One layer of the plane-to-plane chain.  A workgroup (8 waves: 4 feature waves wm x 2 ray waves wn) is PERSISTENT: it walks over ray
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ...; per tile the layer's features come in passes of FP = 128 * NTM features, a wave holding
+// NTM x NTN accumulator tiles of 32 x 32: feature tile tm of wave wm is features tm * 128 + wm * 32 .. + 31 of the pass (so accumulator
+// row tm IS the 128-feature output block tm, whose four 32-feature slabs sit in the four feature waves), ray tile tn is rays
+// wn * 32 * NTN + tn * 32 .. + 31 of the tile's RT = 64 * NTN rays.  Two shapes are used, both with 512 staged rows per slab:
+//   <2, 4>: 256 features x 256 rays (N = 512 layers, two passes), 48 MFMAs per 12 fragment reads;
+//   <3, 2>: 384 features x 128 rays (N = 384 layers, ONE pass: the input planes are read once), 36 MFMAs per 10 fragment reads.
+// Operand slabs go global -> registers -> LDS one slab ahead, one register / one LDS write / one load per group of MFMAs (slots), with a
+// load cursor that runs on across passes and TILES: the next tile's first slabs arrive during this tile's last epilogue, so the start-up
+// latency of a tile (10 us of 60..90 when every tile was its own workgroup) is paid once per workgroup.
+// The slab's ONE barrier sits behind the last slot and behind the second half's fragment reads: a wave passing it has issued all its
+// writes of the next slab and finished reading this slab's stage, so behind it the next stage is complete and this one is free for the
+// slab after next -- and a wave runs from a slab's last MFMA straight into the next slab's fragment reads.
+// Epilogue per pass: bias, ReLU, per-(ray, 128-feature block) power-of-two scale, fp16 split (all waves, in place), then per (block,
+// 128-ray half) LDS staging and coalesced 16-byte stores through the stage just consumed.
+template <int NTM, int NTN>
 __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n_pass, unsigned total_tiles) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kWStage];      // two slab stages; the epilogue staging [256 rays][528 B] aliases them
-  __shared__ float wmaxs[4][256];                                      // per-ray maxima of the four feature waves
-  __shared__ __attribute__((aligned(16))) float cwb[512];              // the pass's reciprocal weight-row scales [256] and biases [256]
-  __shared__ int shl[kMaxGroups][256];                                 // input shifts of the tile's rays, per 128-input block
-  const unsigned w = xcd_remap(blockIdx.x, total_tiles);
-  const int64_t ray0 = (int64_t)w * 256;
+  constexpr int FP = 128 * NTM;          // features per pass
+  constexpr int RT = 64 * NTN;           // rays per tile
+  constexpr int kWL = 2 * NTM;           // weight loads per thread and slab (64 rows each); ray loads: 8 - kWL
+  constexpr int kBarrierGroup = (3 * NTM + 1) > 8 ? (3 * NTM + 1) : 8;      // first MFMA group behind the barrier
+  constexpr int kNS = (kMaxGroups * RT + 511) / 512;                         // input shifts per thread
+  static_assert(FP + RT == kWRows, "a staged slab is 512 rows");
+  __shared__ __attribute__((aligned(16))) char smem[2 * kWStage];      // two slab stages; the epilogue staging [128 rays][528 B] aliases one
+  __shared__ unsigned wmaxb[NTM][RT];                                  // per-(block, ray) maxima (bit patterns of non-negative floats)
+  __shared__ __attribute__((aligned(16))) float cwb[2 * kMaxN];        // the layer's reciprocal weight-row scales [n] and biases [n] (loaded once per workgroup)
+  __shared__ int shl[kMaxGroups][RT];                                  // input shifts of the tile's rays, per 128-input block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;               // wm: 64 features of the pass (MFMA rows), wn: 128 rays (MFMA columns)
+  const int wm = wave >> 1, wn = wave & 1;
   const int ks = A.ks0 + A.ks1;
   const int nb_all = A.n >> 7;
-  f32x16 acc[2][4];
+  f32x16 acc[NTM][NTN];
+  unsigned tile = blockIdx.x;
+  int64_t ray0 = (int64_t)tile * RT;
 
-  for (int i = tid; i < kMaxGroups * 256; i += 512) {
-    const int g = i >> 8;
-    const int64_t cray = min(ray0 + (i & 255), A.m - 1);
-    shl[g][i & 255] = g < A.g0 ? A.s0[cray * A.g0 + g] : (g < A.g0 + A.g1 ? A.s1[cray * A.g1 + (g - A.g0)] : 0);
+  int shn[kNS];      // the shifts this thread moves into the table (first tile: now; later tiles: fetched at the tile switch, stored one slab later)
+#define SDG_SHIFT_FETCH()                                                                                                  \
+  _Pragma("unroll") for (int k_ = 0; k_ < kNS; ++k_) {                                                                     \
+    const int i_ = tid + 512 * k_;                                                                                         \
+    shn[k_] = 0;                                                                                                           \
+    if (i_ < kMaxGroups * RT) {                                                                                            \
+      const int g_ = i_ / RT;                                                                                              \
+      const int64_t cray_ = min(ray0 + (i_ % RT), A.m - 1);                                                                \
+      if (g_ < A.g0) shn[k_] = A.s0[cray_ * A.g0 + g_];                                                                    \
+      else if (g_ < A.g0 + A.g1) shn[k_] = A.s1[cray_ * A.g1 + (g_ - A.g0)];                                               \
+    }                                                                                                                      \
   }
+#define SDG_SHIFT_STORE()                                                                                                  \
+  _Pragma("unroll") for (int k_ = 0; k_ < kNS; ++k_) {                                                                     \
+    const int i_ = tid + 512 * k_;                                                                                         \
+    if (i_ < kMaxGroups * RT) (&shl[0][0])[i_] = shn[k_];                                                                  \
+  }
+  SDG_SHIFT_FETCH()
+  SDG_SHIFT_STORE()
 
-  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 4 instructions x 64
-  // rows per operand.  Addresses are a uniform base (advanced per slab on the scalar unit) + a 32-bit per-thread offset that only changes
-  // with the pass (weights) or the input segment (rays).  Loads are unconditional with clamped rows.
+  // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 8 instructions x 64
+  // rows per slab.  A load's address is a uniform base (scalar unit) + a 32-bit offset, three VALU operations per load; loads are
+  // unconditional with clamped rows.
   const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16;
-  const char* abase0 = A.a0 + (ray0 * A.ks0) * kSlabB;
-  const char* abase1 = A.a1 ? A.a1 + (ray0 * A.ks1) * kSlabB : abase0;
-  const unsigned rmax = (unsigned)min((int64_t)255, A.m - 1 - ray0);      // last valid ray of the tile
-  unsigned lb = 0;      // load cursor: pass and slab of the next fetch
+  unsigned lt = tile, lb = 0;      // load cursor: tile, pass and slab of the next fetch
   int ls = 0;
-  uint4 p0, p1, p2, p3, p4, p5, p6, p7;      // the slab in flight (weights 0..3, rays 4..7); named: an array ended up in scratch
-  // uniform bases and row strides of the cursor's slab; a load's address is base + 32-bit offset, three VALU operations per load
+  const char *abase0, *abase1;
+  unsigned lrmax;                  // last valid ray of the cursor's tile
+#define SDG_TILEBASE()                                                                   \
+  {                                                                                      \
+    const int64_t r0_ = (int64_t)lt * RT;                                                \
+    abase0 = A.a0 + (r0_ * A.ks0) * kSlabB;                                              \
+    abase1 = A.a1 ? A.a1 + (r0_ * A.ks1) * kSlabB : abase0;                              \
+    lrmax = (unsigned)min((int64_t)(RT - 1), A.m - 1 - r0_);                             \
+  }
+  SDG_TILEBASE()
+  uint4 p0, p1, p2, p3, p4, p5, p6, p7;      // the slab in flight (weights 0 .. kWL-1, rays kWL .. 7); named: an array ended up in scratch
 #define SDG_BASES()                                                                                                       \
   const char* wbase = A.wp + (unsigned)ls * kSlabB;                                                                       \
   const bool seg1_ = ls >= A.ks0;                                                                                         \
   const char* abase = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * kSlabB : abase0 + (unsigned)ls * kSlabB;                  \
   const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * kSlabB, wstride = (unsigned)ks * kSlabB;                   \
-  const unsigned wrow0 = lb * 256u, wrmax = (unsigned)A.n - 1u;
+  const unsigned wrow0 = lb * (unsigned)FP, wrmax = (unsigned)A.n - 1u;
 #define SDG_LOAD(J, P)                                                                                                    \
-  P = *reinterpret_cast<const uint4*>((J) < 4 ? wbase + (min(wrow0 + 64u * ((J) & 3) + lrow, wrmax) * wstride + lc16)     \
-                                              : abase + (min(64u * ((J) & 3) + lrow, rmax) * astride + lc16));
+  P = *reinterpret_cast<const uint4*>((J) < kWL ? wbase + (min(wrow0 + 64u * (J) + lrow, wrmax) * wstride + lc16)         \
+                                                : abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));
 #define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
 #define SDG_WRITE(DST, J, P) *reinterpret_cast<uint4*>((DST) + (J) * 64 * kPRow) = P;
 #define SDG_WRITE_ALL(DST) SDG_WRITE(DST, 0, p0) SDG_WRITE(DST, 1, p1) SDG_WRITE(DST, 2, p2) SDG_WRITE(DST, 3, p3) SDG_WRITE(DST, 4, p4) SDG_WRITE(DST, 5, p5) SDG_WRITE(DST, 6, p6) SDG_WRITE(DST, 7, p7)
-#define SDG_ADVANCE()                           \
-  if (++ls == ks) {                             \
-    ls = 0;                                     \
-    lb = lb + 1 < n_pass ? lb + 1 : lb;         \
+// past the last tile the cursor stays on the last tile's last pass (harmless re-reads)
+#define SDG_ADVANCE()                                     \
+  if (++ls == ks) {                                       \
+    ls = 0;                                               \
+    if (++lb == n_pass) {                                 \
+      if (lt + gridDim.x < total_tiles) {                 \
+        lb = 0;                                           \
+        lt += gridDim.x;                                  \
+        SDG_TILEBASE()                                    \
+      } else {                                            \
+        lb = n_pass - 1;                                  \
+      }                                                   \
+    }                                                     \
   }
   {
     SDG_BASES()
@@ -137,136 +184,126 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   __syncthreads();
   const int frow = lane & 31, fk = (lane >> 5) * 16;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NTN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   int buf = 0, s = 0;
   unsigned pass = 0;
-  float creg = 0.f;
+  bool shifts_pending = false;
+  for (int i = tid; i < A.n; i += 512) {
+    cwb[i] = f3_inv_scale(A.wmax[i]);
+    cwb[kMaxN + i] = A.bias[i];
+  }
 #ifdef SDG_DENSE_PROF
-  long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long prof_t[4] = {0, 0, 0, 0};
   const long long prof_start = clock64();
   const long long prof_rt = wall_clock64();
 #endif
-  const int rayl = wn * 128 + (lane & 31);        // this lane's rays: rayl + 32 * tn
-// The barrier sits in the MIDDLE of a slab, behind the last slot: every wave passing it has issued all its writes of the next slab and
-// holds the second half's fragments in registers, i.e. has finished reading this slab's stage.  Behind it the next slab's stage is
-// complete and this slab's stage is free for the slab after next: one barrier per slab, at a point where every wave still has 16
-// MFMAs to issue, and a wave runs from a slab's last MFMA straight into the next slab's fragment reads (with the barrier at the slab's
-// end the matrix pipe drained there: 4300 cycles per slab against 3072 of MFMA work).
-// One slab of MFMAs.  SLOTS: after each group of 4 MFMAs one staging register goes to the idle LDS stage (the slab loaded during the
-// previous iteration) and is re-loaded with its piece of the slab after that -- the loads and LDS writes of all waves are spread over the
-// MFMA time instead of arriving together behind it (measured before: 35 % of a slab's cycles in staging, load issue and the barrier
-// with the matrix pipe idle).  A load has one full slab (48 MFMAs per wave, two waves per SIMD: ~2 us) to come back.
-#ifndef SDG_EXP
-#define SDG_EXP 0
-#endif
-#if SDG_EXP == 1 || SDG_EXP == 3       // timing experiments (wrong results): no loads / no LDS writes in the slots
-#define SDG_XLOAD(J, P)
-#else
-#define SDG_XLOAD(J, P) SDG_LOAD(J, P)
-#endif
-#if SDG_EXP == 2 || SDG_EXP == 3
-#define SDG_XWRITE(D, J, P)
-#else
-#define SDG_XWRITE(D, J, P) SDG_WRITE(D, J, P)
-#endif
+  const int rayl = wn * 32 * NTN + (lane & 31);        // this lane's rays within the tile: rayl + 32 * tn
+// one slot: staging register P of the slab loaded during the previous iteration goes to the idle stage and is re-loaded with its piece of
+// the slab after next (a load has one full slab, ~2 us, to come back); pinned between two groups of MFMAs
 #define SDG_SLOT(J, P)                     \
   {                                        \
     __builtin_amdgcn_sched_barrier(0);     \
-    SDG_XWRITE(dw, J, P)                   \
-    SDG_XLOAD(J, P)                        \
+    SDG_WRITE(dw, J, P)                    \
+    SDG_LOAD(J, P)                         \
     __builtin_amdgcn_sched_barrier(0);     \
   }
-#define SDG_FRAGS(KSTEP)                                                                                                                      \
-  _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                                                          \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) a[t][pl] = *reinterpret_cast<const f16x8_t*>(sw + t * 32 * kPRow + pl * 64 + (KSTEP) * 32); \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + (KSTEP) * 32); \
-  }
-// (weight plane PA, ray plane PB) of feature tile TM against the 4 ray tiles
-#define SDG_MFMA4(TM, PA, PB)                                                                                               \
-  _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                                          \
-    acc[TM][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[TM][PA], b[tn][PB], acc[TM][tn], 0, 0, 0);
-// plane pairs in the order l*h, h*l, h*h -- smallest magnitude first
-#define SDG_SLAB(SL)                                          \
-  {                                                           \
-    f16x8_t a[2][2], b[4][2];                                 \
-    SDG_FRAGS(0)                                              \
-    SDG_MFMA4(0, 1, 0) SL(0, p0) SDG_MFMA4(1, 1, 0) SL(1, p1) \
-    SDG_MFMA4(0, 0, 1) SL(2, p2) SDG_MFMA4(1, 0, 1) SL(3, p3) \
-    SDG_MFMA4(0, 0, 0) SL(4, p4) SDG_MFMA4(1, 0, 0) SL(5, p5) \
-    SDG_FRAGS(1)                                              \
-    SDG_MFMA4(0, 1, 0) SL(6, p6) SDG_MFMA4(1, 1, 0) SL(7, p7) \
-    __syncthreads(); /* the slab's ONE barrier, see below */  \
-    SDG_MFMA4(0, 0, 1) SDG_MFMA4(1, 0, 1)                     \
-    SDG_MFMA4(0, 0, 0) SDG_MFMA4(1, 0, 0)                     \
-  }
-  while (true) {                     // flattened over (pass, slab)
-    const int nfeat = min(256, A.n - (int)pass * 256);       // features of this pass (128 or 256)
-    const bool active = wm * 64 < nfeat;                     // wave-uniform
+  while (true) {                     // flattened over (tile, pass, slab)
     const bool last = s + 1 == ks;
     SDG_T(t0_)
-    if (s == 0) {     // in flight for the whole pass
-      const int f = min((int)pass * 256 + (tid & 255), A.n - 1);
-      const float cw_ = A.wmax[f], cb_ = A.bias[f];      // both against uniform bases (a per-lane pointer select lived in VGPRs, spilled)
-      creg = tid < 256 ? cw_ : cb_;
+    if (s == 1 && shifts_pending) {      // the new tile's shifts (fetched at the switch): visible behind this slab's barrier, first used at slab 4
+      SDG_SHIFT_STORE()
+      shifts_pending = false;
     }
     SDG_BASES()
     char* dw = smem + (buf ^ 1) * kWStage + lrow * kPRow + lc16;
-    if (active) {
-      if ((s & 3) == 0 && s > 0) {       // a new 128-input block: accumulators to its scale (exact powers of two)
-        const int* sp = &shl[0][0] + ((s >> 2) << 8) + rayl;      // one address, constant offsets (separate row / ray indices were hoisted and spilled)
+    if ((s & 3) == 0 && s > 0) {       // a new 128-input block: accumulators to its scale (exact powers of two)
+      unsigned t_ = threadIdx.x;      // opaque copy: computed from it, the address is formed HERE (hoisted out of the loop it was spilled, and
+      asm volatile("" : "+v"(t_));    // the scratch reload's wait drained the operand loads in flight every fourth slab)
+      const int* sp = &shl[0][0] + (s >> 2) * RT + ((t_ >> 6) & 1) * 32 * NTN + (t_ & 31);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          const float fac = pow2i(sp[32 * tn] - sp[32 * tn - 256]);
+      for (int tn = 0; tn < NTN; ++tn) {
+        const float fac = pow2i(sp[32 * tn] - sp[32 * tn - RT]);
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;
+          for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;
+      }
+    }
+    {
+      const char* sw = smem + buf * kWStage + (wm * 32 + frow) * kPRow + fk;
+      const char* sr = smem + buf * kWStage + (FP + wn * 32 * NTN + frow) * kPRow + fk;
+      f16x8_t a[NTM][2], b[NTN][2];
+#pragma unroll
+      for (int kstep = 0; kstep < 2; ++kstep) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+          for (int t = 0; t < NTM; ++t) a[t][pl] = *reinterpret_cast<const f16x8_t*>(sw + t * 128 * kPRow + pl * 64 + kstep * 32);
+#pragma unroll
+          for (int t = 0; t < NTN; ++t) b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + kstep * 32);
+        }
+        // (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) {
+          const int pa = qq == 0 ? 1 : 0, pb = qq == 1 ? 1 : 0;
+#pragma unroll
+          for (int tm = 0; tm < NTM; ++tm) {
+            const int g = (kstep * 3 + qq) * NTM + tm;      // MFMA group (compile-time after unrolling)
+            if (g == kBarrierGroup) __syncthreads();        // the slab's one barrier
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], b[tn][pb], acc[tm][tn], 0, 0, 0);
+            switch (g) {
+              case 0: SDG_SLOT(0, p0) break;
+              case 1: SDG_SLOT(1, p1) break;
+              case 2: SDG_SLOT(2, p2) break;
+              case 3: SDG_SLOT(3, p3) break;
+              case 4: SDG_SLOT(4, p4) break;
+              case 5: SDG_SLOT(5, p5) break;
+              case 6: SDG_SLOT(6, p6) break;
+              case 7: SDG_SLOT(7, p7) break;
+              default: break;
+            }
+          }
         }
       }
-      const char* sw = smem + buf * kWStage + (wm * 64 + frow) * kPRow + fk;
-      const char* sr = smem + buf * kWStage + (256 + wn * 128 + frow) * kPRow + fk;
-      SDG_SLAB(SDG_SLOT)
-    } else {
-      SDG_WRITE_ALL(dw)
-      SDG_LOAD_ALL()
-      __syncthreads();
     }
     SDG_ADVANCE()
     SDG_T(t1_)
-    SDG_ACC(pass == 0 ? 0 : 6, t0_, t1_)
+    SDG_ACC(0, t0_, t1_)
     if (last) {     // the pass is complete: its epilogue borrows the stage just consumed (the other one holds the next pass's first slab)
       char* const stg = smem + buf * kWStage;        // staging [128 rays][528 B]: one (128-feature block, 128-ray half) at a time
-      cwb[tid] = tid < 256 ? f3_inv_scale(creg) : creg;
+      for (int i = tid; i < NTM * RT; i += 512) (&wmaxb[0][0])[i] = 0u;
       __syncthreads();
-      const int f0 = (int)pass * 256;
-      const int nblk = nfeat >> 7;
+      const int f0 = (int)pass * FP;
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       const bool planes_out = A.out_f32 == nullptr;
-      if (active) {
-        // lane: rays rayl + 32 tn, features (of the pass) wm*64 + tm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); acc becomes the layer output in place.
-        // All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed fp32
-        // multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value (4.4 before).
+      {
+        // lane: rays rayl + 32 tn, features (of the pass) tm*128 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); acc becomes the layer output in
+        // place.  All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed
+        // fp32 multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value.
         const int glast = (ks - 1) >> 2;
         const float relu_floor = A.relu ? 0.f : -__builtin_inff();
-        float rmax[4] = {0.f, 0.f, 0.f, 0.f};
-        float ib[4];
+        float ib[NTN];
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) ib[tn] = pow2i(-shl[glast][rayl + 32 * tn]);
+        for (int tn = 0; tn < NTN; ++tn) ib[tn] = pow2i(-shl[glast][rayl + 32 * tn]);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < NTM; ++tm) {
+          float rmax[NTN];
+#pragma unroll
+          for (int tn = 0; tn < NTN; ++tn) rmax[tn] = 0.f;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int fl4 = wm * 64 + tm * 32 + 8 * rg + 4 * (lane >> 5);
-            const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + 256 + fl4);
+            const int fl4 = f0 + tm * 128 + wm * 32 + 8 * rg + 4 * (lane >> 5);
+            const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + kMaxN + fl4);
             const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
             const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
               for (int jp = 0; jp < 2; ++jp) {
                 f32x2_t v = {acc[tm][tn][4 * rg + 2 * jp], acc[tm][tn][4 * rg + 2 * jp + 1]};
@@ -278,28 +315,28 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
                 rmax[tn] = fmaxf(fmaxf(rmax[tn], fabsf(x0)), fabsf(x1));
               }
           }
-        if (planes_out) {
-          // per-ray maximum: the partner lane l ^ 32 holds the other features of the same ray, the block's other feature wave the rest
+          if (planes_out) {
+            // per-(block, ray) maximum: the partner lane l ^ 32 holds the wave's other features of the ray, the other three feature waves
+            // the block's other slabs (LDS maximum on the bit patterns: the values are non-negative)
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn) rmax[tn] = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
-          if (lane < 32) {
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) wmaxs[wm][rayl + 32 * tn] = rmax[tn];
+            for (int tn = 0; tn < NTN; ++tn) {
+              const float r2 = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
+              if (lane < 32) atomicMax(&wmaxb[tm][rayl + 32 * tn], __float_as_uint(r2));
+            }
           }
         }
       }
       __syncthreads();
-      if (active && planes_out) {
-        // every wave splits its values now (in place: 4 values -> 2 registers of h, 2 of l), so that the unit loop below only moves bytes
-        const int bw = wm >> 1;
+      if (planes_out) {
+        // every wave splits its values now (in place: 4 values -> 2 registers of h, 2 of l): the unit loop below only moves bytes
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          const int ray = rayl + 32 * tn;
-          const int sh = p_shift(fmaxf(wmaxs[2 * bw][ray], wmaxs[2 * bw + 1][ray]));
-          const float sc = pow2i(sh);
-          if ((wm & 1) == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + bw] = sh;
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
+          for (int tn = 0; tn < NTN; ++tn) {
+            const int ray = rayl + 32 * tn;
+            const int sh = p_shift(__uint_as_float(wmaxb[tm][ray]));
+            const float sc = pow2i(sh);
+            if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + tm] = sh;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               f16x4 h, l;
@@ -316,73 +353,69 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
               acc[tm][tn][4 * rg + 2] = lb2.x;
               acc[tm][tn][4 * rg + 3] = lb2.y;
             }
-        }
+          }
       }
-      SDG_T(tu0_)
-      SDG_ACC(1, t1_, tu0_)
-      for (int unit = 0; unit < 2 * nblk; ++unit) {         // (128-feature block, 128-ray half): the two waves holding it fill the staging tile
-        const int bsel = unit >> 1, hsel = unit & 1;
-        SDG_T(tu1_)
-        if ((wm >> 1) == bsel && wn == hsel) {
-          const int fw = (wm & 1) * 64;                 // this wave's features within the block
-          if (!planes_out) {
-            float* st = reinterpret_cast<float*>(stg);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+      for (int tm = 0; tm < NTM; ++tm) {                    // unit = (128-feature block tm, 128-ray half): its waves fill the staging tile
+        for (int hsel = 0; hsel < RT / 128; ++hsel) {
+          if (((wn * 32 * NTN) >> 7) == hsel) {
+            const int ru = (rayl & 127);                    // ray within the unit: ru + 32 * tn
+            if (!planes_out) {
+              float* st = reinterpret_cast<float*>(stg);
 #pragma unroll
-              for (int tm = 0; tm < 2; ++tm)
+              for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                  *reinterpret_cast<float4*>(st + ((lane & 31) + 32 * tn) * (kStRow / 4) + fw + tm * 32 + 8 * rg + 4 * (lane >> 5)) =
+                  *reinterpret_cast<float4*>(st + (ru + 32 * tn) * (kStRow / 4) + wm * 32 + 8 * rg + 4 * (lane >> 5)) =
                       float4{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1], acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
-          } else {
+            } else {
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-              for (int tm = 0; tm < 2; ++tm)
+              for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                  const int fl = fw + tm * 32 + 8 * rg + 4 * (lane >> 5);     // feature within the block: slab fl >> 5, position fl & 31
-                  char* d = stg + ((lane & 31) + 32 * tn) * kStRow + (fl >> 5) * kSlabB + (fl & 31) * 2;
+                  // feature wm*32 + 8 rg + 4 (lane>>5) + j of the block: slab wm, position 8 rg + 4 (lane>>5)
+                  char* d = stg + (ru + 32 * tn) * kStRow + wm * kSlabB + (8 * rg + 4 * (lane >> 5)) * 2;
                   *reinterpret_cast<f32x2_t*>(d) = f32x2_t{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1]};
                   *reinterpret_cast<f32x2_t*>(d + 64) = f32x2_t{acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
                 }
+            }
           }
-        }
-        SDG_T(tu2_)
-        SDG_ACC(2, tu1_, tu2_)
-        __syncthreads();
-        SDG_T(tu3_)
-        SDG_ACC(5, tu2_, tu3_)
-        const int fb = f0 + bsel * 128;
-        const int64_t rbase = ray0 + hsel * 128;
-        if (A.out_f32 != nullptr) {
+          __syncthreads();
+          const int fb = f0 + tm * 128;
+          const int64_t rbase = ray0 + hsel * 128;
+          if (!planes_out) {
 #pragma unroll
-          for (int i = tid; i < 128 * 32; i += 512) {
-            const int ray = i >> 5, c = i & 31;
-            if (rbase + ray < A.m)
-              *reinterpret_cast<float4*>(A.out_f32 + (rbase + ray) * A.ldo + fb + c * 4) = reinterpret_cast<const float4*>(stg + ray * kStRow)[c];
-          }
-        } else {
-          const int nslab_out = A.n >> 5;
+            for (int i = tid; i < 128 * 32; i += 512) {
+              const int ray = i >> 5, c = i & 31;
+              if (rbase + ray < A.m)
+                *reinterpret_cast<float4*>(A.out_f32 + (rbase + ray) * A.ldo + fb + c * 4) = reinterpret_cast<const float4*>(stg + ray * kStRow)[c];
+            }
+          } else {
+            const int nslab_out = A.n >> 5;
 #pragma unroll
-          for (int i = tid; i < 128 * 32; i += 512) {
-            const int ray = i >> 5, c = i & 31;
-            if (rbase + ray < A.m)
-              *reinterpret_cast<uint4*>(A.out_planes + ((rbase + ray) * nslab_out + (fb >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stg + ray * kStRow)[c];
+            for (int i = tid; i < 128 * 32; i += 512) {
+              const int ray = i >> 5, c = i & 31;
+              if (rbase + ray < A.m)
+                *reinterpret_cast<uint4*>(A.out_planes + ((rbase + ray) * nslab_out + (fb >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stg + ray * kStRow)[c];
+            }
           }
+          __syncthreads();
         }
-        SDG_T(tu4_)
-        SDG_ACC(4, tu3_, tu4_)
-        __syncthreads();
-        SDG_T(tu5_)
-        SDG_ACC(7, tu4_, tu5_)
       }
-      if (++pass >= n_pass) break;
+      SDG_T(te_)
+      SDG_ACC(1, t1_, te_)
+      if (++pass == n_pass) {      // next tile of this workgroup
+        pass = 0;
+        tile += gridDim.x;
+        if (tile >= total_tiles) break;
+        ray0 = (int64_t)tile * RT;
+        SDG_SHIFT_FETCH()
+        shifts_pending = true;
+      }
 #pragma unroll
-      for (int i_ = 0; i_ < 2; ++i_)
+      for (int i_ = 0; i_ < NTM; ++i_)
 #pragma unroll
-        for (int j_ = 0; j_ < 4; ++j_)
+        for (int j_ = 0; j_ < NTN; ++j_)
 #pragma unroll
           for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;
       s = -1;
@@ -390,19 +423,20 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
     buf ^= 1;
     ++s;
   }
-#undef SDG_SLAB
 #undef SDG_SLOT
-#undef SDG_FRAGS
-#undef SDG_MFMA4
 #undef SDG_LOAD
 #undef SDG_LOAD_ALL
 #undef SDG_WRITE
 #undef SDG_WRITE_ALL
 #undef SDG_BASES
 #undef SDG_ADVANCE
+#undef SDG_TILEBASE
+#undef SDG_SHIFT_FETCH
+#undef SDG_SHIFT_STORE
 #ifdef SDG_DENSE_PROF
-  if (blockIdx.x == total_tiles / 2 && lane == 0) {
-    for (int k = 0; k < 8; ++k) g_dense_prof[wave * 16 + k] = prof_t[k];
+  if (blockIdx.x == gridDim.x / 2 && lane == 0) {
+    g_dense_prof[wave * 16 + 0] = prof_t[0];
+    g_dense_prof[wave * 16 + 1] = prof_t[1];
     g_dense_prof[wave * 16 + 8] = clock64() - prof_start;
     g_dense_prof[wave * 16 + 9] = wall_clock64() - prof_rt;      // 100 MHz
   }
@@ -461,11 +495,29 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
   *reinterpret_cast<f16x8_t*>(d + 64) = l;
 }
 
+int dense_grid(int64_t tiles) {
+  static int cus = 0;      // one persistent workgroup per compute unit (the kernel's 156 KB of LDS allow one)
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return (int)(tiles < cus ? tiles : cus);
+}
+
 int launch_dense(const DenseArgs& A, hipStream_t s) {
-  const int64_t m_tiles = sdg_cdiv(A.m, 256);
-  if (m_tiles <= 0) return 0;
-  if (m_tiles > 0x7fffffffLL) return SIXDGS_E_BADARG;
-  hipLaunchKernelGGL(k_dense_planes, dim3((unsigned)m_tiles), dim3(512), 0, s, A, (unsigned)sdg_cdiv(A.n, 256), (unsigned)m_tiles);
+  if (A.m <= 0) return 0;
+  if (A.ks0 + A.ks1 < 2 || (A.g0 + A.g1) > kMaxGroups || A.n > kMaxN) return SIXDGS_E_BADARG;
+  // N = 384 layers: one pass of 384 features over 128-ray tiles; N = 512: two passes of 256 features over 256-ray tiles
+  const bool wide = A.n % 384 == 0;
+  if (!wide && A.n % 256 != 0) return SIXDGS_E_BADARG;
+  const int64_t tiles = sdg_cdiv(A.m, wide ? 128 : 256);
+  if (tiles > 0x7fffffffLL) return SIXDGS_E_BADARG;
+  const int grid = dense_grid(tiles);
+  if (grid <= 0) return (int)hipErrorInvalidDevice;
+  if (wide) hipLaunchKernelGGL((k_dense_planes<3, 2>), dim3((unsigned)grid), dim3(512), 0, s, A, (unsigned)(A.n / 384), (unsigned)tiles);
+  else hipLaunchKernelGGL((k_dense_planes<2, 4>), dim3((unsigned)grid), dim3(512), 0, s, A, (unsigned)(A.n / 256), (unsigned)tiles);
   SDG_LAUNCH_OK();
   return 0;
 }

@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 h = ctypes.CDLL(lib.LIB_PATH)
 buf = (ctypes.c_longlong * 128)()
 assert h.sixdgs_debug_dense_prof(buf) == 0
-print("wave slabs(pass0) slabs(pass1) | epilogue: transform  stage-write  barrier  copy-out  barrier | total cycles, wall us, GHz   (last layer: 12 slabs x 2 passes, 3 blocks)")
+print("wave   slab loop   epilogues | total cycles, wall us, GHz   (one persistent workgroup of the last layer: k_proj, 12 slabs, one pass of 384 features, 8 tiles of 128 rays)")
 for wv in range(8):
     v = buf[wv * 16: wv * 16 + 16]
-    print(f"{wv:4d} {v[0]:9d} {v[6]:9d} | {v[1]:9d} {v[2]:9d} {v[5]:9d} {v[4]:9d} {v[7]:9d} | {v[8]:8d} {v[9] / 100:7.1f} {v[8] / max(v[9], 1) / 10:5.2f}")
+    print(f"{wv:4d} {v[0]:11d} {v[1]:11d} | {v[8]:9d} {v[9] / 100:8.1f} {v[8] / max(v[9], 1) / 10:5.2f}")
