@@ -665,3 +665,24 @@ def test_plane_chain_keys_on_wide_dynamic_range_inputs(ops, oracle, syn):
     # row-wise: every key row within 5e-6 of its own largest element
     err = np.abs(N(key) - okey).max(axis=1) / np.abs(okey).max(axis=1)
     assert err.max() < 5e-6, err.max()
+
+
+def test_plane_chain_persistent_workgroups_over_many_tiles(ops, oracle, syn):
+    """More ray tiles than compute units: every workgroup of k_dense_planes walks over several tiles (tile switch, the next tile's input
+    shifts, the load cursor running ahead into the next tile) and the last tile is ragged.  Keys of the first, a middle and the last
+    stretch of rays against the oracle's fp32 chain, and the whole set against a second run in small chunks (one tile per workgroup)."""
+    sd = syn.make_scorer_state_dict(5)
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
+    R = 256 * 256 * 3 + 4321                      # > 3 tiles of 256 rays (and > 6 of 128) per workgroup on 256 CUs
+    rays = syn.make_rays(R, 21)
+    rays["ori"] = (rays["ori"] * np.logspace(-2, 2, R)[:, None]).astype(np.float32)
+    o, d, c = G(rays["ori"]), G(rays["dir"]), G(rays["rgb"])
+    _, key = ops.ray_keys(o, d, c, w)
+    assert key.shape == (R, 384) and bool(torch.isfinite(key).all())
+    for lo, hi in ((0, 700), (R // 2 - 300, R // 2 + 300), (R - 4321 - 200, R)):
+        _, okey = oracle.ray_features(rays["ori"][lo:hi], rays["dir"][lo:hi], rays["rgb"][lo:hi], sd)
+        err = np.abs(N(key[lo:hi]) - okey).max(axis=1) / np.abs(okey).max(axis=1)
+        assert err.max() < 5e-6, (lo, err.max())
+    ws = torch.empty(20000 * 1580 * 4, dtype=torch.uint8, device="cuda")
+    _, key2 = ops.ray_keys(o, d, c, w, workspace=ws, max_chunk=20000)
+    assert torch.equal(key2, key)
