@@ -10,6 +10,7 @@ per batch.
 from __future__ import annotations
 
 import math
+import os
 import time
 from statistics import mean
 from typing import List, Optional
@@ -183,11 +184,17 @@ def test_pose_estimation(
     verbose: bool = True,
     token_override: Optional[List[torch.Tensor]] = None,
     up_override: Optional[torch.Tensor] = None,
+    save_dir: Optional[str] = None,
 ):
     """See module docstring.  `token_override` / `up_override` inject the boundary's image-side inputs
-    (tokens [T,398] per image, camera-up [B,3]) -- used by the parity fixtures, where DINOv2 is absent."""
-    if save or save_all:
-        raise NotImplementedError("the reference's save= branch writes to a hard-coded developer path (test.py:206-209)")
+    (tokens [T,398] per image, camera-up [B,3]) -- used by the parity fixtures, where DINOv2 is absent.
+
+    `save` / `save_all` (test.py:94-106,137-140,164-166,202-214): the per-image dump of everything the estimate was made from
+    (`sample_results_<img_idx>.th`, image 0 only unless `save_all`), same keys as the reference.  The reference writes into a
+    developer's home directory; here the directory is `save_dir`, else $SIXDGS_SAVE_DIR, else ./sample_results."""
+    if save:
+        save_dir = save_dir or os.environ.get("SIXDGS_SAVE_DIR") or os.path.join(os.getcwd(), "sample_results")
+        os.makedirs(save_dir, exist_ok=True)
     id_module.eval()
     dev = rays_ori.device
     if not rays_ori.is_cuda:
@@ -210,7 +217,19 @@ def test_pose_estimation(
             has_alpha = [np.asarray(c.image).shape[-1] == 4 for c in cams]
             toks, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] if a else None for p, a in zip(prepared, has_alpha)])
             up = id_module.camera_up(fmaps)
-        idx, weights, pred_scores = id_module.score_tokens(toks, rays_ori, rays_dirs, rays_rgb, k, want_scores=loss_fn is not None)
+        saving = [bool(save) and (b0 + i == 0 or bool(save_all)) for i in range(nb)]
+        idx, weights, pred_scores = id_module.score_tokens(toks, rays_ori, rays_dirs, rays_rgb, k, want_scores=loss_fn is not None or any(saving))
+        dumps = [None] * nb
+        for i in range(nb):
+            if saving[i]:       # test.py:94-106
+                dumps[i] = {
+                    "gt_pose": gt[i].cpu(), "camera_intrinsic": Ks[i].cpu(),
+                    "all_rays_ori": rays_ori.cpu(), "all_rays_dirs": rays_dirs.cpu(), "all_rays_rgb": rays_rgb.cpu(),
+                    "obs_img": None if token_override is not None else prepared[i][0].cpu(),
+                    "mask_img": None if token_override is not None else prepared[i][1].cpu(),
+                    "topk_nonunique_ray_idx": idx[i].cpu(), "topk_nonunique_weights": weights[i].cpu(),
+                    "all_predict_weights": pred_scores[i].cpu(),
+                }
         avg_score = [-1.0] * nb
         recall = [-1.0] * nb
         if loss_fn is not None:  # test.py:108-142: evaluate the GROUND-TRUTH top-k instead of the prediction
@@ -224,6 +243,8 @@ def test_pose_estimation(
                 ti, tw = ops.topk(target_scores, k)
                 new_idx.append(ti)
                 new_w.append(tw)
+                if saving[i]:   # test.py:137-140
+                    dumps[i].update(all_target_weights=target_scores.cpu(), loss=avg_score[i], recall=recall[i])
             idx, weights = torch.stack(new_idx), torch.stack(new_w)
         sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt)
         c2w = sol["c2w"].cpu()
@@ -232,6 +253,19 @@ def test_pose_estimation(
         w_mean = (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1)).cpu()  # weights.mean() over kept rays
         nk = sol["n_kept"].cpu()
         for i in range(nb):
+            if saving[i]:       # test.py:157-166,202-214: the duplicate-origin filter restated on the 100 selected rays, for the dump only
+                sel_o = rays_ori[idx[i]]
+                uniq, counts = torch.unique(sel_o, return_counts=True, dim=0)
+                keep = torch.isin(sel_o, uniq[counts == 1], assume_unique=True).any(dim=1)
+                wf = sol["w_final"][i]
+                watch = torch.multiply(rays_dirs[idx[i]], wf[:, None]).sum(dim=0)
+                watch = torch.divide(watch, torch.linalg.norm(watch, dim=-1, keepdim=True))
+                dumps[i].update(topk_unique_ray_idx=idx[i][keep].cpu(), topk_unique_weights=weights[i][keep].cpu(),
+                                topk_unique_weights_after_exclusion=wf[keep].cpu(), pred_camera_optical_center=sol["centre"][i].cpu(),
+                                pred_camera_watch_dir=(-watch).cpu(), pred_c2w_matrix=c2w[i].clone(), model_up=model_up.cpu())
+                torch.save(dumps[i], os.path.join(save_dir, f"sample_results_{b0 + i}.th"))
+                if verbose:
+                    print("Sample result saved")
             st = int(status[i])
             if verbose:
                 if st & 4:

@@ -134,6 +134,47 @@ def test_a24_test_pose_estimation(pkg, e2e):
     assert len(back) == n and np.array(back[0]["pred_c2w"]).shape == (4, 4) and back[0]["frame_id"] == 0
 
 
+def test_a24_save_and_save_all_dump(pkg, e2e, tmp_path):
+    """test.py:94-106,137-140,164-166,202-214: `save=True` dumps image 0, `save_all=True` every image, as sample_results_<i>.th with the
+    reference's keys (into `save_dir` instead of the reference's hard-coded home directory); the dump agrees with the returned results and
+    with the golden top-100 of the prediction."""
+    from oracle.standin_loss import line_distance_loss
+    g, idm, cams = e2e
+    n = int(g["e2e_n"])
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    toks = [G(g[f"e2e{i}_tokens"]) for i in range(n)]
+    ups = torch.stack([G(g[f"e2e{i}_up"]) for i in range(n)])
+    d1 = tmp_path / "first_only"
+    res, *_ = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 2.0, 0.0]), token_override=toks, up_override=ups, verbose=False,
+                                       batch_size=3, save=True, save_dir=str(d1))
+    assert sorted(os.listdir(d1)) == ["sample_results_0.th"]
+    d = torch.load(d1 / "sample_results_0.th")
+    assert set(d.keys()) == {"gt_pose", "camera_intrinsic", "all_rays_ori", "all_rays_dirs", "all_rays_rgb", "obs_img", "mask_img",
+                             "topk_nonunique_ray_idx", "topk_nonunique_weights", "all_predict_weights", "topk_unique_ray_idx",
+                             "topk_unique_weights", "topk_unique_weights_after_exclusion", "pred_camera_optical_center",
+                             "pred_camera_watch_dir", "pred_c2w_matrix", "model_up"}
+    assert torch.equal(d["pred_c2w_matrix"], torch.tensor(res[0]["pred_c2w"]))
+    assert torch.allclose(d["model_up"], torch.tensor([0.0, 1.0, 0.0]))                       # normalised (test.py:40)
+    assert d["all_predict_weights"].shape == (ori.shape[0],) and d["topk_nonunique_ray_idx"].shape == (100,)
+    assert torch.equal(d["all_predict_weights"][d["topk_nonunique_ray_idx"]], d["topk_nonunique_weights"])
+    assert rel_err(N(d["all_predict_weights"]), g["e2e0_scores"]) < 2e-5
+    kept = d["topk_unique_ray_idx"]
+    assert 0 < kept.numel() <= 100 and bool(torch.isin(kept, d["topk_nonunique_ray_idx"]).all())
+    w = d["topk_unique_weights_after_exclusion"]
+    assert w.shape == kept.shape and abs(float(w.sum()) - 1.0) < 1e-5 and bool((w >= 0).all())
+    assert torch.allclose(d["pred_camera_optical_center"], d["pred_c2w_matrix"][:3, 3], atol=1e-6)
+    assert abs(float(torch.linalg.norm(d["pred_camera_watch_dir"])) - 1.0) < 1e-5
+    d2 = tmp_path / "all"
+    res2, *_ = pkg.test_pose_estimation(cams, idm, ori, dr, rgb, torch.tensor([0.0, 1.0, 0.0]), loss_fn=line_distance_loss, token_override=toks,
+                                        up_override=ups, verbose=False, batch_size=3, save=True, save_all=True, save_dir=str(d2))
+    assert sorted(os.listdir(d2)) == [f"sample_results_{i}.th" for i in range(n)]
+    for i in range(n):
+        di = torch.load(d2 / f"sample_results_{i}.th")
+        assert {"all_target_weights", "loss", "recall"} <= set(di.keys())
+        assert di["loss"] == res2[i]["scores_loss"] and di["recall"] == res2[i]["recall"]
+        assert torch.equal(di["pred_c2w_matrix"], torch.tensor(res2[i]["pred_c2w"]))
+
+
 def test_a24_loss_fn_branch(pkg, e2e, golden):
     """test.py:108-142: with a loss_fn the loop scores the prediction (scores_loss, recall -- including the reference's quirk of
     comparing positions 0..99 with ray ids) and then solves the pose from the top-100 of the TARGET scores.  The reference ran
