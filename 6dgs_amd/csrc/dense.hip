@@ -54,6 +54,8 @@ struct DenseArgs {
   float* out_f32;        // [M][ldo] or null (exactly one of out_planes / out_f32)
   int64_t ldo;
   int relu;
+  float* out_tile_inv;   // or null.  Non-null (with out_planes, N = 384): the planes are the SCORER's key planes -- one power-of-two scale per
+                         // tile of 128 rays (largest magnitude in [2^13, 2^14)), out_tile_inv[tile] = its reciprocal; out_shift is not written
 };
 
 constexpr int kMaxGroups = 6;
@@ -96,6 +98,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   __shared__ unsigned wmaxb[NTM][RT];                                  // per-(block, ray) maxima (bit patterns of non-negative floats)
   __shared__ __attribute__((aligned(16))) float cwb[2 * kMaxN];        // the layer's reciprocal weight-row scales [n] and biases [n] (loaded once per workgroup)
   __shared__ int shl[kMaxGroups][RT];                                  // input shifts of the tile's rays, per 128-input block
+  __shared__ unsigned tile_max;                                        // key-plane mode: the tile's largest magnitude (bit pattern)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ks = A.ks0 + A.ks1;
@@ -277,6 +280,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
     if (last) {     // the pass is complete: its epilogue borrows the stage just consumed (the other one holds the next pass's first slab)
       char* const stg = smem + buf * kWStage;        // staging [128 rays][528 B]: one (128-feature block, 128-ray half) at a time
       for (int i = tid; i < NTM * RT; i += 512) (&wmaxb[0][0])[i] = 0u;
+      const bool tile_mode = NTM == 3 && NTN == 2 && A.out_tile_inv != nullptr;       // the one-pass 384 x 128 shape only (compiled out of the other: its register budget is spent)
+      if (tid == 0) tile_max = 0u;
       __syncthreads();
       const int f0 = (int)pass * FP;
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -315,7 +320,13 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
                 rmax[tn] = fmaxf(fmaxf(rmax[tn], fabsf(x0)), fabsf(x1));
               }
           }
-          if (planes_out) {
+          if (tile_mode) {
+            float r2 = rmax[0];
+#pragma unroll
+            for (int tn = 1; tn < NTN; ++tn) r2 = fmaxf(r2, rmax[tn]);
+            r2 = sdg_wave_max(r2);
+            if (lane == 0) atomicMax(&tile_max, __float_as_uint(r2));
+          } else if (planes_out) {
             // per-(block, ray) maximum: the partner lane l ^ 32 holds the wave's other features of the ray, the other three feature waves
             // the block's other slabs (LDS maximum on the bit patterns: the values are non-negative)
 #pragma unroll
@@ -334,9 +345,22 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #pragma unroll
           for (int tn = 0; tn < NTN; ++tn) {
             const int ray = rayl + 32 * tn;
-            const int sh = p_shift(__uint_as_float(wmaxb[tm][ray]));
-            const float sc = pow2i(sh);
-            if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + tm] = sh;
+            int sh;
+            if (tile_mode) {      // the scale rule of k_split_tiles_f16 (score.hip), on the same fp32 values: identical planes
+              const float m = __uint_as_float(tile_max);
+              sh = 0;
+              if (m > 0.f && m < INFINITY) {
+                int e;
+                frexpf(m, &e);
+                sh = 14 - e;
+                sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+              }
+              if (tid == 0 && tm == 0 && tn == 0) A.out_tile_inv[ray0 / RT] = ldexpf(1.f, -sh);
+            } else {
+              sh = p_shift(__uint_as_float(wmaxb[tm][ray]));
+              if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + tm] = sh;
+            }
+            const float sc = tile_mode ? ldexpf(1.f, sh) : pow2i(sh);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               f16x4 h, l;
@@ -509,6 +533,7 @@ int dense_grid(int64_t tiles) {
 int launch_dense(const DenseArgs& A, hipStream_t s) {
   if (A.m <= 0) return 0;
   if (A.ks0 + A.ks1 < 2 || (A.g0 + A.g1) > kMaxGroups || A.n > kMaxN) return SIXDGS_E_BADARG;
+  if (A.out_tile_inv && (A.n != 384 || !A.out_planes)) return SIXDGS_E_BADARG;      // a key tile = one workgroup tile of the 384 x 128 shape
   // N = 384 layers: one pass of 384 features over 128-ray tiles; N = 512: two passes of 256 features over 256-ray tiles
   const bool wide = A.n % 384 == 0;
   if (!wide && A.n % 256 != 0) return SIXDGS_E_BADARG;
@@ -554,8 +579,8 @@ int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipSt
 size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 4 + 4) * sizeof(int); }
 
 // ori/dir/rgb of m rays -> fp32 keys kdst [m][384] (row stride 384).  ws: dense_chain_bytes_per_ray() * m bytes, 256-B aligned.
-int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* ws,
-                hipStream_t s) {
+int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* kplanes,
+                float* kinv, char* ws, hipStream_t s) {
   char* xp = ws;
   char* hp1 = xp + (size_t)m * 5 * kSlabB;
   char* hp2 = hp1 + (size_t)m * 16 * kSlabB;
@@ -566,16 +591,19 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
                ok = o4 + (size_t)384 * 16 * kSlabB;
   hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m * 20, 256)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);
   int st;
-  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1};
+  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr};
   if ((st = launch_dense(l1, s))) return st;
-  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1};
+  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr};
   if ((st = launch_dense(l2, s))) return st;
-  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1};
+  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr};
   if ((st = launch_dense(l3, s))) return st;
   // layer 4 has 384 outputs: 3 blocks; its planes reuse hp2 with 12 slabs per ray
-  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0};
+  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr};
   if ((st = launch_dense(l4, s))) return st;
-  DenseArgs l5 = {wplanes + ok, w->mk, w->bk, hp2, sb, nullptr, nullptr, 12, 0, 3, 0, m, 384, nullptr, nullptr, kdst, SIXDGS_D, 0};
+  // k_proj: fp32 keys, or (kplanes) straight the scorer's key planes -- a 128-ray tile of the 384 x 128 shape IS a key tile, so the split
+  // kernel and the fp32 keys' trip through HBM drop out
+  DenseArgs l5 = {wplanes + ok, w->mk, w->bk, hp2, sb, nullptr, nullptr, 12, 0, 3, 0, m, 384, kplanes, nullptr, kplanes ? nullptr : kdst, SIXDGS_D, 0,
+                  kplanes ? kinv : nullptr};
   return launch_dense(l5, s);
 }
 

@@ -442,12 +442,16 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
     // without a caller buffer for fp32 keys the chunk lands in h1 (free after layer 4) and only the planes persist
     float* kdst = key ? key + r0 * SIXDGS_D : h1;     // (the plane-to-plane chain below redirects it)
     const bool want_key = key || key_planes;
+    bool fused_planes = false;
     if (f3 && want_key && !feat && w->planes) {
       // plane-to-plane chain (dense.hip): no fp32 activation through HBM, nothing split in a main loop; fp32 keys land in the
       // caller's buffer or at the head of the workspace, the planes and shifts of the layers behind them
       float* kd = key ? key + r0 * SIXDGS_D : x;
       char* pws = reinterpret_cast<char*>(x + (size_t)chunk * SIXDGS_D);
-      if ((st = dense_chain(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, w, reinterpret_cast<const char*>(w->planes), kd, pws, s))) return st;
+      fused_planes = f16 && !key;      // only the planes are wanted: k_proj writes them itself (identical to the split of its fp32 keys)
+      if ((st = dense_chain(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, w, reinterpret_cast<const char*>(w->planes), kd,
+                            fused_planes ? (char*)key_planes + (size_t)r0 * 1536 : nullptr, fused_planes ? key_inv_scale + r0 / 128 : nullptr, pws, s)))
+        return st;
       kdst = kd;
     } else if (f3) {
       if ((st = sixdgs_ray_encode(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, x, stream))) return st;
@@ -488,7 +492,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
         if ((st = launch_linear(g5, w->bk, false, kdst, SIXDGS_D, s, mma_mode))) return st;
       }
     }
-    if (want_key) {
+    if (want_key && !fused_planes) {
       if (f16) st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
       else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
       if (st) return st;

@@ -215,3 +215,35 @@ def test_select_sample_indices_and_batched_tokens_host_logic():
     assert torch.equal(t[1], torch.cat([f[1], pe], dim=-1)) and torch.equal(t.dense()[2], t[2])
     sub = t[torch.tensor([2, 0])]
     assert isinstance(sub, bb.BatchedTokens) and torch.equal(sub.feats, f[[2, 0]]) and [x.shape for x in t] == [(256, 398)] * 3
+
+
+def test_dense_kernel_register_budget():
+    """k_dense_planes<2,4> sits on the 256-register line: a few more live values and hipcc parks the operand staging registers in scratch, inside
+    the slab loop (measured: 2x slower layers).  The resource report of the cross-compile must show the 384 x 128 instance without scratch and
+    the 256 x 256 instance with no more than its known cold spills, and no scratch access between the MFMAs of the slab loop."""
+    import subprocess
+    import tempfile
+    b = importlib.import_module("6dgs_amd.build")
+    src = os.path.join(b.CSRC, "dense.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        base = [b.HIPCC, *[f for f in b.FLAGS if not f.startswith("-DSDG_")], "--cuda-device-only"]
+        rep = subprocess.run(base + ["-c", src, "-o", os.path.join(tmp, "dense.o"), "-Rpass-analysis=kernel-resource-usage"],
+                             capture_output=True, text=True, check=True).stderr
+        asm = os.path.join(tmp, "dense.s")
+        subprocess.run(base + ["-S", src, "-o", asm], capture_output=True, text=True, check=True)
+        text = open(asm).read()
+    scratch = {}
+    for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", rep, re.S):
+        scratch[m.group(1)] = int(m.group(2))
+    wide = [v for k, v in scratch.items() if "k_dense_planesILi3ELi2" in k]
+    square = [v for k, v in scratch.items() if "k_dense_planesILi2ELi4" in k]
+    assert wide == [0], scratch
+    assert len(square) == 1 and square[0] <= 160, scratch
+    for tag in ("k_dense_planesILi2ELi4", "k_dense_planesILi3ELi2"):
+        body = text[text.index("_ZN12_GLOBAL__N_114" + tag):]
+        body = body[:body.index("s_endpgm")].splitlines()
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_f16" in l]
+        n_per_slab = 48 if "2ELi4" in tag else 36
+        assert len(mfma) == n_per_slab, (tag, len(mfma))                    # one copy of the slab
+        inside = [l for l in body[mfma[0]:mfma[-1]] if "scratch_" in l]
+        assert not inside, (tag, inside[:3])

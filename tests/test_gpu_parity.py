@@ -686,3 +686,34 @@ def test_plane_chain_persistent_workgroups_over_many_tiles(ops, oracle, syn):
     ws = torch.empty(20000 * 1580 * 4, dtype=torch.uint8, device="cuda")
     _, key2 = ops.ray_keys(o, d, c, w, workspace=ws, max_chunk=20000)
     assert torch.equal(key2, key)
+
+
+def test_k_proj_writes_the_key_planes_itself(ops, syn):
+    """want_key=False, want_planes=True (the key cache): the last layer of the plane chain emits the scorer's tile-scaled fp16 key planes and
+    the reciprocal tile scales directly (one workgroup tile of 128 rays x 384 features is one key tile).  Bit-identical to splitting the fp32
+    keys with sixdgs_split_planes_f16, including a ragged last tile, chunked runs and a tile of zeros."""
+    sd = syn.make_scorer_state_dict(11)
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
+    prev = ops.get_mma_mode()
+    ops.set_mma_mode(ops.MMA_F16X3)
+    try:
+        _k_proj_planes_cases(ops, syn, w)
+    finally:
+        ops.set_mma_mode(prev)
+
+
+def _k_proj_planes_cases(ops, syn, w):
+    for R, chunk in ((128 * 301 + 77, 262144), (128 * 301 + 77, 128 * 90), (5, 262144), (128, 262144)):
+        rays = syn.make_rays(R, 31)
+        rays["ori"] = (rays["ori"] * np.logspace(-2, 3, R)[:, None]).astype(np.float32)
+        o, d, c = G(rays["ori"]), G(rays["dir"]), G(rays["rgb"])
+        _, key, (planes_a, inv_a) = ops.ray_keys(o, d, c, w, want_key=True, want_planes=True, max_chunk=chunk)       # fp32 keys + split kernel
+        _, none, (planes_b, inv_b) = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, max_chunk=chunk)    # fused
+        assert none is None
+        assert torch.equal(inv_a, inv_b), (R, chunk)
+        assert torch.equal(planes_a, planes_b), (R, chunk)
+        # the planes decode to the keys: (h + l) * inv_scale within 2^-21 of the tile's largest magnitude
+        pl = planes_b.view(torch.float16).view(R, 12, 2, 32).float()
+        dec = (pl[:, :, 0] + pl[:, :, 1]).reshape(R, 384) * inv_b.repeat_interleave(128)[:R, None]
+        tile_max = torch.zeros((R + 127) // 128, device="cuda").scatter_reduce(0, torch.arange(R, device="cuda") // 128, key.abs().amax(dim=1), "amax")
+        assert float(((dec - key).abs().amax(dim=1) / tile_max.repeat_interleave(128)[:R]).max()) < 2.0 ** -20
