@@ -467,34 +467,61 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #endif
 }
 
-// a12 as planes: x[R][5 slabs][2 planes][32] (141 inputs, zero padded to 160), one shift per ray from the bound max(1, |coordinates|)
+// a12 as planes: x[R][5 slabs][2 planes][32] (141 inputs, zero padded to 160), one shift per ray from the bound max(1, |coordinates|).
+// One workgroup = 64 rays.  The 66 (component, frequency) arguments of a ray give sine AND cosine with one argument reduction (sincosf:
+// the thread-per-8-inputs form this replaces called sinf / cosf 132 times per ray, each with its own reduction -- coordinates times 2^7
+// reach 1e5 rad), staged as fp32 in LDS [ray][161] (odd stride: consecutive rays on consecutive banks), then split 8 inputs at a time.
+constexpr int kEncRays = 64;
 __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restrict__ ori, const float* __restrict__ dir, const float* __restrict__ rgb,
                                                            int64_t R, char* __restrict__ xp, int* __restrict__ xs) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (ray, group of 8 inputs): 20 groups per ray
-  if (i >= R * 20) return;
-  const int64_t ray = i / 20;
-  const int g8 = (int)(i - ray * 20);
-  const float p[3] = {ori[3 * ray], ori[3 * ray + 1], ori[3 * ray + 2]};
-  const float d[3] = {dir[3 * ray], dir[3 * ray + 1], dir[3 * ray + 2]};
-  const float c[3] = {rgb[3 * ray], rgb[3 * ray + 1], rgb[3 * ray + 2]};
-  float m = 1.f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(p[a]), fmaxf(fabsf(d[a]), fabsf(c[a]))));
-  const int sh = p_shift(m);
-  const float sc = pow2i(sh);
-  f16x8_t h, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int col = g8 * 8 + e;
-    const float x = (col < SIXDGS_RAY_IN_PAD ? ray_input_element(p, d, c, col) : 0.f) * sc;
-    const _Float16 hh = (_Float16)x;
-    h[e] = hh;
-    l[e] = (_Float16)(x - (float)hh);
+  __shared__ float X[kEncRays][161];
+  __shared__ float src[kEncRays][9];      // p, d, c
+  const int tid = threadIdx.x;
+  const int64_t ray0 = (int64_t)blockIdx.x * kEncRays;
+  const int n = (int)min((int64_t)kEncRays, R - ray0);
+  for (int i = tid; i < kEncRays * 9; i += 256) {
+    const int r = i / 9, a = i - r * 9;
+    const int64_t gr = ray0 + min(r, n - 1);
+    const float* q = a < 3 ? ori : (a < 6 ? dir : rgb);
+    const float v = q[3 * gr + (a % 3)];
+    src[r][a] = v;
+    X[r][a] = v;                                                   // columns 0..8: the raw coordinates (ray_preprocessor.py:36-44)
   }
-  char* dst = xp + (ray * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
-  *reinterpret_cast<f16x8_t*>(dst) = h;
-  *reinterpret_cast<f16x8_t*>(dst + 64) = l;
-  if (g8 == 0) { xs[2 * ray] = sh; xs[2 * ray + 1] = sh; }
+  for (int i = tid; i < kEncRays * 19; i += 256) X[i / 19][141 + i % 19] = 0.f;      // padding columns 141..159
+  __syncthreads();
+  for (int i = tid; i < kEncRays * 66; i += 256) {
+    const int r = i % kEncRays, k = i / kEncRays;                   // k: p 0..23 (8 frequencies x 3), d 24..47, c 48..65 (6 x 3)
+    const int grp = k < 24 ? 0 : (k < 48 ? 1 : 2);
+    const int F = grp == 2 ? 6 : 8, o = k - grp * 24;
+    const int comp = o / F, f = o - comp * F;
+    const float v = src[r][grp * 3 + comp] * (float)(1 << f);
+    float sn, cs;
+    sincosf(v, &sn, &cs);
+    const int col = 9 + grp * 48 + comp * F + f;                    // sines, then (3 F further) the cosines of the group
+    X[r][col] = sn;
+    X[r][col + 3 * F] = cs;
+  }
+  __syncthreads();
+  for (int i = tid; i < n * 20; i += 256) {
+    const int r = i / 20, g8 = i - r * 20;
+    float m = 1.f;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) m = fmaxf(m, fabsf(src[r][a]));
+    const int sh = p_shift(m);
+    const float sc = pow2i(sh);
+    f16x8_t h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = X[r][g8 * 8 + e] * sc;
+      const _Float16 hh = (_Float16)x;
+      h[e] = hh;
+      l[e] = (_Float16)(x - (float)hh);
+    }
+    char* dst = xp + ((ray0 + r) * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
+    *reinterpret_cast<f16x8_t*>(dst) = h;
+    *reinterpret_cast<f16x8_t*>(dst + 64) = l;
+    if (g8 == 0) { xs[2 * (ray0 + r)] = sh; xs[2 * (ray0 + r) + 1] = sh; }
+  }
 }
 
 // weights fp32 [n][ld] (columns c0 .. c0 + kcols of every row; zero beyond) -> planes [n][ks_total][128 B] at slab offset s_off, scaled by
@@ -589,7 +616,7 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
   int* sb = sa + 4 * m;
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
                ok = o4 + (size_t)384 * 16 * kSlabB;
-  hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m * 20, 256)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);
+  hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);
   int st;
   DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr};
   if ((st = launch_dense(l1, s))) return st;
