@@ -196,16 +196,41 @@ int launch_linear(const GemmOperands& g, const float* bias, bool relu, float* y,
 // ------------------------------------------------------------------------------------------------
 // a12: x[R,144]
 // ------------------------------------------------------------------------------------------------
+// One workgroup = 64 rays; one sincosf per (component, frequency) -- 66 per ray instead of 132 separate sinf / cosf calls with their own
+// argument reductions -- staged in LDS [ray][145] and written as the block's 64 x 144 contiguous floats.
 __global__ void __launch_bounds__(256) k_ray_encode(const float* __restrict__ ori, const float* __restrict__ dir,
                                                      const float* __restrict__ rgb, int64_t R, float* __restrict__ x) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R * SIXDGS_RAY_IN_PAD) return;
-  const int64_t ray = i / SIXDGS_RAY_IN_PAD;
-  const int col = (int)(i - ray * SIXDGS_RAY_IN_PAD);
-  const float p[3] = {ori[3 * ray], ori[3 * ray + 1], ori[3 * ray + 2]};
-  const float d[3] = {dir[3 * ray], dir[3 * ray + 1], dir[3 * ray + 2]};
-  const float c[3] = {rgb[3 * ray], rgb[3 * ray + 1], rgb[3 * ray + 2]};
-  x[i] = ray_input_element(p, d, c, col);
+  constexpr int kRays = 64, kLd = SIXDGS_RAY_IN_PAD;
+  __shared__ float X[kRays][kLd + 1];
+  __shared__ float src[kRays][9];      // p, d, c
+  const int tid = threadIdx.x;
+  const int64_t ray0 = (int64_t)blockIdx.x * kRays;
+  const int n = (int)min((int64_t)kRays, R - ray0);
+  for (int i = tid; i < kRays * 9; i += 256) {
+    const int r = i / 9, a = i - r * 9;
+    const int64_t gr = ray0 + min(r, n - 1);
+    const float* q = a < 3 ? ori : (a < 6 ? dir : rgb);
+    const float v = q[3 * gr + (a % 3)];
+    src[r][a] = v;
+    X[r][a] = v;
+  }
+  for (int i = tid; i < kRays * (kLd - 141); i += 256) X[i / (kLd - 141)][141 + i % (kLd - 141)] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < kRays * 66; i += 256) {
+    const int r = i % kRays, k = i / kRays;                   // k: p 0..23 (8 frequencies x 3), d 24..47, c 48..65 (6 x 3)
+    const int grp = k < 24 ? 0 : (k < 48 ? 1 : 2);
+    const int F = grp == 2 ? 6 : 8, o = k - grp * 24;
+    const int comp = o / F, f = o - comp * F;
+    const float v = src[r][grp * 3 + comp] * (float)(1 << f);
+    float sn, cs;
+    sincosf(v, &sn, &cs);
+    const int col = 9 + grp * 48 + comp * F + f;              // same columns as ray_input_element (device_math.h)
+    X[r][col] = sn;
+    X[r][col + 3 * F] = cs;
+  }
+  __syncthreads();
+  float* dst = x + ray0 * kLd;
+  for (int i = tid; i < n * kLd; i += 256) dst[i] = X[i / kLd][i % kLd];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +376,7 @@ int sixdgs_ray_encode(const float* ori, const float* dir, const float* rgb, int6
   SDG_CHECK_ARG(r >= 0);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && x);
-  hipLaunchKernelGGL(k_ray_encode, dim3((unsigned)sdg_cdiv(r * SIXDGS_RAY_IN_PAD, 256)), dim3(256), 0, sdg_stream(stream), ori, dir,
+  hipLaunchKernelGGL(k_ray_encode, dim3((unsigned)sdg_cdiv(r, 64)), dim3(256), 0, sdg_stream(stream), ori, dir,
                      rgb, r, x);
   SDG_LAUNCH_OK();
   return 0;
