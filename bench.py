@@ -295,8 +295,8 @@ def main():
         "median_step": {"ms": round(1e3 * med, 3), "poses_per_s": round(world * args.batch / med, 4), "n": len(per_step),
                         "min_ms": round(1e3 * min(per_step), 3), "max_ms": round(1e3 * max(per_step), 3),
                         "note": "rank-0 wall time of each timed step (every step ends with the poses on the host)"},
-        "arithmetic": ("fp32 results; q.K^T as 2 power-of-two-scaled fp16 planes x 3 MFMA terms, dense layers as 3 bf16 planes x 6 MFMA "
-                       "terms, fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
+        "arithmetic": ("fp32 results; q.K^T and the ray MLP / k_proj as 2 power-of-two-scaled fp16 planes x 3 MFMA terms (q_proj, CNN: 3 bf16 planes x 6 "
+                       "terms), fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
                        + ("; select path: no logits stored, candidates re-scored in fp32 (nothing below fp32 on the path)" if path.startswith("select") else
                           ("; logits travel between the two scorer passes as 24-bit fixed point, absolute error <= 2^-20 per logit "
                            "(fp32_logits_mode = the same run without that narrowing)" if mode == ops.MMA_F16X3 else ""))),
