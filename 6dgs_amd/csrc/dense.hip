@@ -13,12 +13,8 @@
 // per column tile -- the per-ray rescale is one factor per lane -- and 4 consecutive features per register group, i.e. 8-byte pieces
 // of a ray's plane row.
 //
-// Tile 128 features x 128 rays, 4 waves (2 x 2), K in slabs of 32: both operand slabs (2 planes x 64 B per row) go global ->
-// registers -> LDS (row stride 144 B, conflict-free ds_read_b128) with NO arithmetic on the way; double-buffered, one barrier per
-// slab.  Epilogue through LDS (the main loop's buffers are free by then): bias, ReLU, per-ray block maximum (lane, l ^ 32 partner,
-// the two feature waves), scale, split, staged as [ray][4 slabs][2 planes][32] = 512 contiguous bytes per ray and written to the
-// next layer's plane array as 16-byte pieces, 1 KiB contiguous per wave instruction.  The last layer (k_proj) leaves fp32 rows
-// instead, which k_split_tiles_f16 turns into the scorer's per-128-RAY-tile planes.
+// Tiles, staging, barrier placement, persistence and the epilogue: see k_dense_planes below.  The last layer (k_proj) leaves either fp32
+// rows or -- on the key-cache path -- the scorer's per-128-RAY-tile key planes and reciprocal tile scales themselves.
 #include "gemm_kernel.h"
 #include "device_math.h"
 #include "dense.h"
