@@ -717,3 +717,28 @@ def _k_proj_planes_cases(ops, syn, w):
         dec = (pl[:, :, 0] + pl[:, :, 1]).reshape(R, 384) * inv_b.repeat_interleave(128)[:R, None]
         tile_max = torch.zeros((R + 127) // 128, device="cuda").scatter_reduce(0, torch.arange(R, device="cuda") // 128, key.abs().amax(dim=1), "amax")
         assert float(((dec - key).abs().amax(dim=1) / tile_max.repeat_interleave(128)[:R]).max()) < 2.0 ** -20
+
+
+def test_plane_chain_randomised_sizes_and_chunks(ops, syn):
+    """Ray counts around the tile sizes of both dense kernels (128 / 256 rays), the persistent grid (256 workgroups) and random chunkings:
+    the fused key planes equal the split of the fp32 keys, and every chunking gives the same keys bit for bit."""
+    sd = syn.make_scorer_state_dict(17)
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
+    rng = np.random.default_rng(123)
+    sizes = [1, 127, 128, 129, 255, 256, 257, 383, 32768 + 5, 65536 + 1, 256 * 257 - 3] + [int(x) for x in rng.integers(2, 90000, 6)]
+    prev = ops.get_mma_mode()
+    ops.set_mma_mode(ops.MMA_F16X3)
+    try:
+        for R in sizes:
+            rays = syn.make_rays(R, 40 + R % 7)
+            o, d, c = G(rays["ori"]), G(rays["dir"]), G(rays["rgb"])
+            _, key, (pa, ia) = ops.ray_keys(o, d, c, w, want_key=True, want_planes=True)
+            chunk = int(rng.integers(1, 40)) * 128
+            _, key2, (pb, ib) = ops.ray_keys(o, d, c, w, want_key=True, want_planes=True, max_chunk=chunk)
+            _, _, (pc, ic) = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, max_chunk=chunk)
+            assert torch.equal(key, key2), (R, chunk)
+            assert torch.equal(pa, pb) and torch.equal(ia, ib), (R, chunk)
+            assert torch.equal(pa, pc) and torch.equal(ia, ic), (R, chunk)
+            assert bool(torch.isfinite(key).all())
+    finally:
+        ops.set_mma_mode(prev)
