@@ -881,9 +881,9 @@ static int inv3_lu(const float* A, float* inv) {
 void o_pose_from_topk(const float* rays_ori, const float* rays_dir, const int64_t* idx, const float* weights, int k,
                       const float* up, float* c2w, float* centre_out, float* w_final, uint8_t* keep, int* flags,
                       int* n_kept) {
-  float* so = (float*)malloc(sizeof(float) * 3 * (size_t)k);
-  float* sd = (float*)malloc(sizeof(float) * 3 * (size_t)k);
-  float* w = (float*)malloc(sizeof(float) * (size_t)k);
+  float* so = (float*)calloc(3 * (size_t)(k > 0 ? k : 1), sizeof(float));
+  float* sd = (float*)calloc(3 * (size_t)(k > 0 ? k : 1), sizeof(float));
+  float* w = (float*)calloc((size_t)(k > 0 ? k : 1), sizeof(float));
   for (int i = 0; i < k; ++i)
     for (int c = 0; c < 3; ++c) so[3 * i + c] = rays_ori[3 * idx[i] + c];
   int kept = o_unique_origin_filter(so, k, keep);
