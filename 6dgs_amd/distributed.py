@@ -17,8 +17,9 @@ of the per-rank top-k candidates -- a few KB per image, latency-bound, the only 
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Optional, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -39,7 +40,11 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tup
             backend = os.environ.get("SIXDGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # The default watchdog timeout (10 min with nccl = RCCL) is shorter than what a rank may legitimately wait for in a
+        # collective: the evaluation sweep trains a missing id_module.th on rank 0 (1500 x 32 steps) while the others wait in
+        # agree().  SIXDGS_DIST_TIMEOUT_S overrides (seconds).
+        timeout = datetime.timedelta(seconds=int(os.environ.get("SIXDGS_DIST_TIMEOUT_S", str(12 * 3600))))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 
@@ -150,6 +155,28 @@ def gather_results(results: list, dst: int = 0) -> list:
 def barrier():
     if is_dist():
         dist.barrier()
+
+
+def agree(fn: Callable, what: str = "", device=None):
+    """Runs the rank-local stage `fn()` (NO collectives inside) and then lets the ranks agree on whether it worked: an all-reduce
+    (MAX) of a failure flag.  A RuntimeError -- the one exception the reference's sweep survives per scene
+    (pretrain_eval_attention.py:243-244): out of memory, an unreadable scene, a missing backbone -- on ANY rank is raised on
+    EVERY rank (the failing rank re-raises its own, the others a RuntimeError naming the stage), so that all ranks leave the
+    scene together and the next scene's collectives pair up again.  Without a process group: plain fn()."""
+    err, out = None, None
+    try:
+        out = fn()
+    except RuntimeError as e:
+        err = e
+    if is_dist():
+        dev = "cpu" if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and err is None:
+            raise RuntimeError(f"6dgs_amd: another rank failed during '{what}'; rank {dist.get_rank()} leaves the scene with it")
+    if err is not None:
+        raise err
+    return out
 
 
 def backend_name() -> str:

@@ -69,60 +69,77 @@ def explore_model(model, **emission):
     return generate_all_possible_rays(model, sample_quadricell_targets=50, **kw)
 
 
-def _scene_on_every_rank(checkpoint_filepath, sh_degree, device):
-    scene = load_model(checkpoint_filepath, device, sh_degrees=sh_degree) if dd.rank() == 0 else None
-    return dd.broadcast_scene(scene, 0, device=device)
-
-
 def pretrain_single_object(checkpoint_filepath: str, checkpoint_args: "dotdict[str, Any]", exp_dir_filepath: str, object_id: str, category_name: str,
                            starting_seed: int, lock_backbone: bool = True, device: str = "cuda", *, emission: Optional[dict] = None,
                            n_iterations: int = 1500, skip_train: bool = False, batch_size: int = 16, backbone: Optional[torch.nn.Module] = None):
     """pretrain_eval_attention.py:31-160 for one scene; returns the result dicts of the inference pass for ALL test views (rank 0;
-    other ranks return their own block)."""
+    other ranks return their own block).
+
+    Multi-rank: the scene is walked in STAGES.  A stage is rank-local work that may fail (`dd.agree`: the ranks all-reduce a
+    failure flag behind it and leave the scene TOGETHER on a RuntimeError of any of them); the collectives (scene / weight
+    broadcast, seed, result gather) sit between the stages, where every rank is known to arrive.  Rank 0 trains a missing
+    checkpoint inside a stage while the others wait in that stage's all-reduce (the process group's timeout is set for it,
+    distributed.init_from_env)."""
     torch.manual_seed(starting_seed)
     print("data_path: ", checkpoint_args.source_path)
     emission = dict(EMISSION, **(emission or {}))
-    gs_model = _scene_on_every_rank(checkpoint_filepath, checkpoint_args.sh_degree if checkpoint_args.sh_degree is not None else 3, device)
-    if checkpoint_args.fps_sampling is None:
-        checkpoint_args.fps_sampling = -1
-    scene_info = load_data(checkpoint_args)
-    id_module = IdentificationModule(backbone_type="dino", backbone=backbone).to(device).train()
-    start_iterations = 0
     ckpt_path = os.path.join(exp_dir_filepath, "id_module.th")
-    if os.path.exists(ckpt_path):
-        print("Checkpoint already exist, skip training phase")
-        ckpt = torch.load(ckpt_path, map_location=device)
-        id_module.load_state_dict(ckpt["model_state_dict"])
-        start_iterations = ckpt["epoch"]
-    if not skip_train and start_iterations < n_iterations and dd.rank() == 0:
-        train_id_module(ckpt_path, device, id_module, partial(explore_model, gs_model, **emission), scene_info, object_id, category_name,
-                        start_iterations=start_iterations, lock_backbone=lock_backbone, n_iterations=n_iterations)
+
+    def stage_load():
+        scene = load_model(checkpoint_filepath, device, sh_degrees=checkpoint_args.sh_degree if checkpoint_args.sh_degree is not None else 3) \
+            if dd.rank() == 0 else None
+        if checkpoint_args.fps_sampling is None:
+            checkpoint_args.fps_sampling = -1
+        info = load_data(checkpoint_args)
+        module = IdentificationModule(backbone_type="dino", backbone=backbone).to(device).train()
+        start = 0
+        if os.path.exists(ckpt_path):
+            print("Checkpoint already exist, skip training phase")
+            ckpt = torch.load(ckpt_path, map_location=device)
+            module.load_state_dict(ckpt["model_state_dict"])
+            start = ckpt["epoch"]
+        return scene, info, module, start
+
+    scene, scene_info, id_module, start_iterations = dd.agree(stage_load, "load scene, cameras and checkpoint", device)
+    gs_model = dd.broadcast_scene(scene, 0, device=device)
+
+    def stage_train():
+        if not skip_train and start_iterations < n_iterations and dd.rank() == 0:
+            train_id_module(ckpt_path, device, id_module, partial(explore_model, gs_model, **emission), scene_info, object_id, category_name,
+                            start_iterations=start_iterations, lock_backbone=lock_backbone, n_iterations=n_iterations)
+
+    dd.agree(stage_train, "train the scorer (rank 0)", device)
     dd.broadcast_module(id_module, 0)
     id_module.eval()
     id_module.invalidate_caches()
     print("Training complete starting testing phase...")
     if dd.world() > 1:       # every rank must emit the SAME rays (the subsample is a torch.randperm): one seed from rank 0's generator
         torch.manual_seed(dd.broadcast_int(int(torch.randint(0, 2**31 - 1, (1,)).item()), 0, device))
-    rays_ori, rays_dirs, rays_rgb = explore_model(gs_model, **emission)
-    model_up = torch.from_numpy(np.mean(np.asarray([c.R[:3, 1] for c in scene_info.train_cameras], dtype=np.float32), axis=0)).to(device)
     lo, hi = dd.shard_range(len(scene_info.test_cameras), dd.rank(), dd.world())
-    mine = scene_info.test_cameras[lo:hi]
-    print("Testing overfit performances...")
-    _, o_t, o_a, o_s, o_r = test_pose_estimation(mine, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id=object_id,
-                                                 category_id=category_name, loss_fn=DistanceBasedScoreLoss(), batch_size=batch_size)
-    print("Overfit AVG translation error: ", o_t)
-    print("Overfit AVG angular error: ", o_a)
-    print("Overfit AVG score error: ", o_s)
-    print("Overfit recall: ", o_r)
-    print("Testing performances on same points...")
-    results, t_t, t_a, t_s, t_r = test_pose_estimation(mine, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id=object_id,
-                                                       category_id=category_name, save=False, save_all=False, batch_size=batch_size)
-    for r in results:
-        r["frame_id"] += lo                  # frame ids count the scene's test views, not the rank's block
-    print("Test AVG translation error: ", t_t)
-    print("Test AVG angular error: ", t_a)
-    print("Test AVG score error: ", t_s)
-    print("Test recall: ", t_r)
+
+    def stage_evaluate():
+        rays_ori, rays_dirs, rays_rgb = explore_model(gs_model, **emission)
+        model_up = torch.from_numpy(np.mean(np.asarray([c.R[:3, 1] for c in scene_info.train_cameras], dtype=np.float32), axis=0)).to(device)
+        mine = scene_info.test_cameras[lo:hi]
+        print("Testing overfit performances...")
+        _, o_t, o_a, o_s, o_r = test_pose_estimation(mine, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id=object_id,
+                                                     category_id=category_name, loss_fn=DistanceBasedScoreLoss(), batch_size=batch_size)
+        print("Overfit AVG translation error: ", o_t)
+        print("Overfit AVG angular error: ", o_a)
+        print("Overfit AVG score error: ", o_s)
+        print("Overfit recall: ", o_r)
+        print("Testing performances on same points...")
+        results, t_t, t_a, t_s, t_r = test_pose_estimation(mine, id_module, rays_ori, rays_dirs, rays_rgb, model_up, sequence_id=object_id,
+                                                           category_id=category_name, save=False, save_all=False, batch_size=batch_size)
+        for r in results:
+            r["frame_id"] += lo                  # frame ids count the scene's test views, not the rank's block
+        print("Test AVG translation error: ", t_t)
+        print("Test AVG angular error: ", t_a)
+        print("Test AVG score error: ", t_s)
+        print("Test recall: ", t_r)
+        return results
+
+    results = dd.agree(stage_evaluate, "emit rays and evaluate the test views", device)
     return dd.gather_results(results, 0)
 
 

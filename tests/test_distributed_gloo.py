@@ -59,6 +59,24 @@ def _worker(rank, world, port, q):
             assert allp is None
         # 4. timing reduction
         assert dd.max_over_ranks(float(rank), "cpu") == float(world - 1)
+        # 5. a stage that fails on ONE rank is left by BOTH (a rank-local RuntimeError -- OOM, unreadable scene -- used to
+        #    send that rank on to the next scene's broadcast while the other still sat in this scene's collectives)
+        assert dd.agree(lambda: rank * 10, "fine") == rank * 10
+
+        def stage():
+            if rank == 1:
+                raise RuntimeError("rank 1 ran out of memory")
+            return "done"
+
+        try:
+            dd.agree(stage, "evaluate")
+            raised = None
+        except RuntimeError as e:
+            raised = str(e)
+        assert raised is not None and (("rank 1 ran out of memory" in raised) if rank == 1 else ("another rank failed during 'evaluate'" in raised))
+        t = torch.tensor([float(rank + 1)])
+        torch.distributed.broadcast(t, 0)                 # the next scene's first collective pairs up again
+        assert float(t) == 1.0
         dd.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover

@@ -1,0 +1,147 @@
+"""a23 / f2 on the MI355X: the image side (BackboneWrapper: resize / crop / normalise, patch tokens, grid position encoding,
+mask -> token selection; ViT-S/14 forward; the batched + hipGraph form the hot path uses) against
+  * the reference's own output (goldens g7 `e2e{i}_tokens / _fmap`, g11 `m{i}_*`: BackboneWrapper.forward of
+    pose_estimation/backbone.py:82-139 captured by oracle/gen_golden.py with a fixed patch-embed stand-in, because DINOv2
+    weights do not exist offline) -- the same three comparisons tests/test_backbone_golden.py makes on CPU tensors, here with
+    module and inputs on cuda:0;
+  * a plain PyTorch fp32 CPU evaluation of the same ViT-S/14 module (the reference of the op for the part the goldens cannot
+    pin: the 12 transformer blocks);
+  * the eager per-image path, for the batched + hipGraph image side of estimate_poses.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from test_backbone_golden import PatchEmbedStandIn, cameras
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wrapper():
+    bb = importlib.import_module("6dgs_amd.backbone")
+    return bb.BackboneWrapper("dino", backbone=PatchEmbedStandIn()).eval().to("cuda")
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_gpu_tokens_and_feature_map_match_the_reference(wrapper, syn, golden):
+    g = golden("g7_e2e")
+    tp = importlib.import_module("6dgs_amd.test")
+    for i, cam in enumerate(cameras(syn)):
+        img, mask = tp.prepare_image(cam["image"], "cuda")
+        assert img.is_cuda and mask.is_cuda
+        with torch.no_grad():
+            t_pe, t_flat, fmap = wrapper(img, mask)
+        assert t_pe.is_cuda
+        ref_tok, ref_fmap = g[f"e2e{i}_tokens"], g[f"e2e{i}_fmap"]
+        assert tuple(t_pe.shape) == ref_tok.shape, (i, t_pe.shape, ref_tok.shape)          # the SAME tokens survive the mask
+        assert tuple(fmap.shape) == ref_fmap.shape == (384, 16, 16)
+        scale = np.abs(ref_tok[:, :384]).max()
+        assert np.abs(N(t_pe)[:, :384] - ref_tok[:, :384]).max() / scale < 2e-5               # patch features
+        assert np.abs(N(t_pe)[:, 384:] - ref_tok[:, 384:]).max() < 1e-6                       # 14 position-encoding channels
+        assert rel_err(N(fmap), ref_fmap) < 2e-5
+        assert torch.equal(t_flat, t_pe[:, :384])
+
+
+def test_gpu_mask_to_token_selection_matches_the_reference(wrapper, syn, golden):
+    """Structured alpha masks (disc, soft-edged half plane, small box): 140 / 128 / 56 of 256 tokens survive in the reference
+    (backbone.py:86-114: two bilinear resizes, > 0.1, boolean selection in row-major order).  Same tokens, same order, same
+    values -- with the resizes and the selection running on the GPU."""
+    g = golden("g11_backbone_masks")
+    tp = importlib.import_module("6dgs_amd.test")
+    kept = []
+    for i, cam in enumerate(syn.make_masked_cameras(9, 120)):
+        img, mask = tp.prepare_image(cam["image"], "cuda")
+        with torch.no_grad():
+            t_pe, t_flat, fmap = wrapper(img, mask)
+        ref = g[f"m{i}_tokens"]
+        assert tuple(t_pe.shape) == ref.shape, (i, t_pe.shape, ref.shape)
+        assert np.abs(N(t_pe)[:, 384:] - ref[:, 384:]).max() < 1e-6                           # the grid positions of the survivors
+        assert np.abs(N(t_pe)[:, :384] - ref[:, :384]).max() / np.abs(ref[:, :384]).max() < 2e-5
+        assert rel_err(N(t_flat), g[f"m{i}_flat"]) < 2e-5
+        assert rel_err(N(fmap), g[f"m{i}_fmap"]) < 2e-5
+        kept.append(t_pe.shape[0])
+    assert kept == [140, 128, 56]
+
+
+def test_gpu_batched_image_side_equals_the_per_image_path(wrapper, syn):
+    tp = importlib.import_module("6dgs_amd.test")
+    cams = cameras(syn)[:3]
+    imgs = [tp.prepare_image(c["image"], "cuda")[0] for c in cams]
+    with torch.no_grad():
+        feats = wrapper.features_from_norm(wrapper.preprocess_batch(torch.stack(imgs)))
+        toks, fmaps = wrapper.assemble_batch(feats)
+        for i, im in enumerate(imgs):
+            t_pe, _, fmap = wrapper(im, None)
+            assert torch.allclose(toks[i], t_pe, atol=1e-6) and torch.allclose(fmaps[i], fmap, atol=1e-6)
+
+
+def test_gpu_vit_s14_matches_the_cpu_evaluation_of_the_same_module(syn):
+    """The 12 transformer blocks (no golden can pin them: no DINOv2 weights offline): the module's forward on the MI355X
+    (rocBLAS GEMMs, SDPA, the patch embedding as one GEMM) against plain PyTorch fp32 on the CPU, same seeded weights, real
+    preprocessed images.  LayerScale is set away from 1 and the class token / biases away from 0 so that no term drops out."""
+    bb = importlib.import_module("6dgs_amd.backbone")
+    tp = importlib.import_module("6dgs_amd.test")
+    torch.manual_seed(5)
+    vit = bb.ViTS14().eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for name, p in vit.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif name.endswith("bias") or name == "cls_token":
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    w_cpu = bb.BackboneWrapper("dino", backbone=vit).eval()
+    imgs = [tp.prepare_image(c["image"], "cpu")[0] for c in cameras(syn)[:3]]
+    with torch.no_grad():
+        x = w_cpu.preprocess_batch(torch.stack(imgs))
+        ref = vit.forward_features(x)["x_norm_patchtokens"]
+        vit_gpu = bb.ViTS14().eval()
+        vit_gpu.load_state_dict(vit.state_dict())
+        vit_gpu = vit_gpu.to("cuda")
+        got = vit_gpu.forward_features(x.to("cuda"))["x_norm_patchtokens"]
+    assert got.is_cuda and got.shape == ref.shape == (3, 256, 384)
+    assert rel_err(N(got), ref.numpy()) < 1e-4, rel_err(N(got), ref.numpy())
+    # and through the wrapper, from the uint8 image: preprocessing on the GPU too
+    w_gpu = bb.BackboneWrapper("dino", backbone=vit_gpu).eval().to("cuda")
+    with torch.no_grad():
+        t_gpu, _, f_gpu = w_gpu(tp.prepare_image(cameras(syn)[0]["image"], "cuda")[0], None)
+        t_cpu, _, f_cpu = w_cpu(imgs[0], None)
+    assert rel_err(N(t_gpu), t_cpu.numpy()) < 1e-4 and rel_err(N(f_gpu), f_cpu.numpy()) < 1e-4
+
+
+def test_gpu_image_side_graph_equals_the_eager_per_image_path(syn):
+    """What estimate_poses replays per batch (test.py: _ImageSideGraph -- uint8 -> fp32, resize / crop / normalise, ViT-S/14 on
+    the whole batch, token assembly, camera-up CNN, one hipGraph) against the eager per-image path the reference has
+    (backbone.py:82-114 + camera_direction_network.py:81-90 per image): tokens and camera-up within 1e-5 / 1e-4 (the batched GEMMs
+    take other rocBLAS tiles than the per-image ones); replaying with NEW images gives those images' tokens."""
+    pkg = importlib.import_module("6dgs_amd")
+    tp = importlib.import_module("6dgs_amd.test")
+    sd = syn.make_scorer_state_dict(0, with_cnn=True)
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    idm = idm.to("cuda").eval()
+
+    def batch(seed):
+        return [torch.from_numpy(np.ascontiguousarray(np.array(c["image"]))).to("cuda") for c in syn.make_cameras(4, seed, width=200, height=160)]
+
+    for seed in (31, 32):                      # second round = a replay of the captured graph on other pixels
+        images = batch(seed)
+        assert tp.prime_image_graph(idm, images), "the image side did not capture into a hipGraph"
+        cache = idm.__dict__["_image_side_graph"]
+        tokens, up = cache.run(idm, images)
+        assert cache.graph is not None and not cache.failed
+        dense = tokens.dense() if hasattr(tokens, "dense") else tokens
+        for i, im in enumerate(images):
+            img, _ = tp.prepare_image_device(im)
+            with torch.no_grad():
+                t_pe, _, fmap = idm.backbone_wrapper(img, None)
+                up_i = idm.camera_up(fmap[None])[0]
+            assert rel_err(N(dense[i]), N(t_pe)) < 1e-5, (seed, i, rel_err(N(dense[i]), N(t_pe)))
+            assert np.abs(N(up[i]) - N(up_i)).max() < 1e-4, (seed, i)

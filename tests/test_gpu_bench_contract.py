@@ -42,6 +42,16 @@ def test_bench_single_gpu_json_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["ranks_seen"] == 1 and d["median_step"]["n"] == 2 and d["config"]["preset"] == "headline"
+    # the second half of BASELINE.json's metric ("mean rot/trans err") and the parity of the run, from the line alone
+    p = d["parity_vs_oracle"]
+    assert "error" not in p, p
+    assert p["sample_rays"] == 100000 and p["top100_identical"] is True and p["score_rel_err"] < 1e-5
+    assert p["two_pass"]["value_rel_err"] < 1e-5 and p["select"]["value_rel_err"] < 1e-5 and p["select"]["top100_identical"] is True
+    assert p["rot_err_deg"] < 1e-2 and p["trans_err"] < 1e-4 * max(1.0, abs(p["pose"]["vs_synthetic_gt"]["oracle"]["trans_err"]))
+    g = p["pose"]["vs_synthetic_gt"]
+    assert abs(g["hip"]["rot_err_deg"] - g["oracle"]["rot_err_deg"]) < 1e-2 and abs(g["hip"]["trans_err"] - g["oracle"]["trans_err"]) < 1e-3
+    assert d["metric_errors"]["mean_rot_err_deg_vs_reference_outputs"] == p["rot_err_deg"] and "errors_vs_synthetic_gt" not in d
+    assert d["reference_mode"]["value"] > 0 and 20000 < d["reference_mode"]["rays"] < 40000
 
 
 @pytest.mark.timeout(500)

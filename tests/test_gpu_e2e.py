@@ -420,6 +420,68 @@ def test_evaluation_sweep_sharded_over_two_ranks_gives_the_same_file(pkg, syn, t
         assert np.abs(np.asarray(a["pred_c2w"]) - np.asarray(b["pred_c2w"])).max() < 1e-5
 
 
+MIP360_SCENES = ("bicycle", "bonsai", "counter", "garden", "kitchen", "room", "stump")       # tools/launch_all_mip_training.sh:3-9
+TT_SCENES = ("Barn", "Caterpillar", "Family", "Ignatius", "Truck")                              # tools/launch_all_tanks_and_temple_training.sh:3-7
+
+
+def test_cfg5_stand_in_sweep_of_twelve_scenes_one_rank_and_two(pkg, syn, tmp_path):
+    """BASELINE.json configs[4] ("full Mip-NeRF360 + Tanks&Temples eval sweep, all scenes, all test views") with stand-ins for what
+    cannot exist offline (trained 3DGS scenes, id_module.th, DINOv2): the reference's TWELVE experiment directories -- 7 in the
+    Mip-NeRF360 / COLMAP layout (binary and text models alternating), 5 in the Tanks&Temples / NSVF layout, each with its own
+    `cfg_args`, PLY (two iterations, the highest wins) and dataset of its own size -- through `pretrain_eval_attention.main`
+    (pretrain_eval_attention.py:200-248) as ONE process and as TWO ranks (test views in contiguous blocks per scene, scene and weights
+    broadcast from rank 0, per-scene result gather): the two results files list the same 12 scenes in the same order with the same
+    views and poses.  A thirteenth directory holds a truncated PLY: every rank leaves that scene together (rank 0 fails to read it,
+    the others learn it through distributed.agree) and the sweep carries on -- the reference's per-scene `except RuntimeError`."""
+    import json
+    import subprocess
+    import sys
+    root = str(tmp_path)
+    expect = []
+    for i, name in enumerate(MIP360_SCENES):
+        srcs = syn.write_dataset_fixtures(os.path.join(root, "data", f"m{i}"), 10 + i, n_views=17 + 8 * (i % 3), width=56 + 14 * (i % 2), height=42)
+        _write_experiment(root, syn, pkg, f"mip_360_{name}_m{i:03d}", srcs["colmap_bin" if i % 2 == 0 else "colmap_txt"], 1500 + 250 * i, 20 + i)
+        expect.append((f"mip_360_{name}", f"m{i:03d}", -(-(17 + 8 * (i % 3)) // 8)))          # llffhold 8: every 8th view is a test view
+    for i, name in enumerate(TT_SCENES):
+        srcs = syn.write_dataset_fixtures(os.path.join(root, "data", f"t{i}"), 40 + i, n_views=10 + 2 * i, width=64, height=48)
+        _write_experiment(root, syn, pkg, f"tt_{name}_t{i:03d}", srcs["tt"], 1200 + 300 * i, 60 + i)
+        expect.append((f"tt_{name}", f"t{i:03d}", None))
+    # a scene whose checkpoint cannot be read
+    _write_experiment(root, syn, pkg, "tt_Broken_zz99", srcs["tt"], 500, 99)
+    for it in ("iteration_30000", "iteration_7000"):
+        ply = os.path.join(root, "output", "tt_Broken_zz99", "point_cloud", it, "point_cloud.ply")
+        blob = open(ply, "rb").read()
+        open(ply, "wb").write(blob[: len(blob) // 2])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SIXDGS_RANDOM_BACKBONE="1", SIXDGS_DIST_BACKEND="gloo", SIXDGS_FORCE_DEVICE="0")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs, logs = [], []
+    for n, launcher in ((1, []), (2, ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29549"])):
+        out = os.path.join(root, f"cfg5_{n}.json")
+        p = subprocess.run([sys.executable, "-W", "ignore", *launcher, os.path.join(repo, "pretrain_eval_attention.py"), "--exp_path", os.path.join(root, "output"),
+                            "--out_path", out, "--data_type", "all", "--skip_train", "--batch_size", "2", "--max_ellipsoids", "-1"], cwd=repo, env=env,
+                           capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, p.stderr[-3000:]
+        outs.append(json.load(open(out)))
+        logs.append(p.stdout + p.stderr)
+    one, two = outs
+    scenes = []
+    for r in one:
+        if not scenes or scenes[-1][:2] != (r["category_name"], r["sequence_id"]):
+            scenes.append([r["category_name"], r["sequence_id"], 0])
+        scenes[-1][2] += 1
+    assert [tuple(s[:2]) for s in scenes] == [e[:2] for e in sorted(expect)], scenes            # 12 scenes, directory order; the broken one is absent
+    for s, e in zip(scenes, sorted(expect)):
+        assert e[2] is None or s[2] == e[2], (s, e)
+    assert all(s[2] >= 1 for s in scenes) and "zz99" not in {r["sequence_id"] for r in one}
+    assert len(one) == len(two) and [(r["category_name"], r["sequence_id"], r["frame_id"]) for r in one] == [(r["category_name"], r["sequence_id"], r["frame_id"]) for r in two]
+    for a, b in zip(one, two):
+        assert a["gt_c2w"] == b["gt_c2w"]
+        assert np.abs(np.asarray(a["pred_c2w"]) - np.asarray(b["pred_c2w"])).max() < 1e-5
+        assert (a["loss"] == b["loss"]) or abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
+    assert "another rank failed during" in logs[1]          # rank 1 left the broken scene because rank 0 could not read it
+
+
 def test_fused_position_encoding_and_q_proj(pkg, syn):
     """for images that keep all 256 tokens the [B,256,398] concatenation of patch features and grid position
     encoding is not built; q = feats . Wq[:, :384]^T + (pe . Wq[:, 384:]^T + bq).  Same q as the reference's Linear(398 -> 384) on
