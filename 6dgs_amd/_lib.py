@@ -20,7 +20,7 @@ sz = C.c_size_t
 
 
 PROFILE_SLOTS = 128
-ABI_VERSION = 3          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
+ABI_VERSION = 4          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
 
 
 class Profile(C.Structure):
@@ -63,12 +63,13 @@ SIGNATURES = {
     "sixdgs_score_pass2": (i32, [vp, vp, i32, i32, i64, i32, vp, vp, vp, vp, sz, vp, i32]),
     "sixdgs_score_topk_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile), i32]),
     "sixdgs_score_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
-    "sixdgs_score_select": (i32, [vp, vp, vp, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp, C.POINTER(Profile)]),
+    "sixdgs_score_select": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp, C.POINTER(Profile)]),
+    "sixdgs_key_planes_norm_max": (i32, [vp, vp, i64, vp, vp]),
     "sixdgs_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_select_candidates_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_select_begin": (i32, [vp, vp, i32, vp, vp, i64, i64, vp, vp, vp, sz, vp]),
     "sixdgs_select_sweep": (i32, [vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, i64, vp, sz, vp, C.POINTER(Profile)]),
-    "sixdgs_select_candidates": (i32, [vp, i64, i64, vp, i32, vp, i32, i32, vp, vp, vp, sz, vp]),
+    "sixdgs_select_candidates": (i32, [vp, i64, i64, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
     "sixdgs_select_rescore": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "sixdgs_linear_splitk_workspace_bytes": (sz, [i64, i32, i32]),
     "sixdgs_linear_splitk": (i32, [vp, i64, i32, i64, vp, i64, vp, i32, i32, vp, i64, i32, vp, sz, vp, i32]),

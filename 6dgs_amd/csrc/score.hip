@@ -1343,36 +1343,91 @@ __global__ void __launch_bounds__(kT) k_sel_accumulate(const float* __restrict__
   gsum[i] += stats_g[i * 2 + 1];
 }
 
+// max over the rows of |x_row| for the values the scaled fp16 planes hold, x = (h + l) * inv_scale[row / 128]: one wave per row (48 lanes
+// x one 16-byte chunk of h and its partner of l).  *out is UPDATED (bit pattern of a non-negative float: atomicMax): callers that feed
+// the scene in chunks accumulate.  The result is rounded UP (x (1 + 2^-12) covers the fp32 sum of 384 squares) -- it is used as a bound.
+__global__ void __launch_bounds__(256) k_plane_norm_max(const char* __restrict__ planes, const float* __restrict__ inv_scale, int64_t rows,
+                                                        unsigned* __restrict__ out) {
+  const int lane = sdg_lane();
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + sdg_wave(), nw = (int64_t)gridDim.x * 4;
+  float best = 0.f;
+  for (int64_t row = wave0; row < rows; row += nw) {
+    float ss = 0.f;
+    if (lane < 48) {
+      const char* p = planes + row * kRowF + (lane >> 2) * kSlabF + (lane & 3) * 16;
+      const f16x8 h = *reinterpret_cast<const f16x8*>(p), l = *reinterpret_cast<const f16x8*>(p + 64);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = (float)h[e] + (float)l[e];       // exact: 22 significant bits
+        ss = __builtin_fmaf(x, x, ss);
+      }
+    }
+    ss = sdg_wave_sum(ss);
+    best = fmaxf(best, sqrtf(ss) * inv_scale[row >> 7]);
+  }
+  if (lane == 0 && best > 0.f) atomicMax(out, __float_as_uint(best * 1.000244140625f));
+}
+
 // per image: g_min / g_max over its tokens, the candidate threshold on U and the validity of the bounds.
-// info[bl][4] = {threshold on U, flag, -, -}: flag 0 ok, 1 = no tokens (all scores are exactly 0), 2 = bounds unusable (overflow / NaN)
+// info[bl][4] = {threshold on U, flag, eps, x}: flag 0 ok, 1 = no tokens (all scores are exactly 0), 2 = bounds unusable (overflow / NaN)
+//
+// The slack of the threshold is DERIVED, not tuned.  What is compared are two evaluations of the same quantity: U[r]
+// from the sweep (matrix-core accumulation, fp32 epilogue) and the candidates' exact re-score (fp64 accumulation of the same plane
+// products, the same epilogue constants).  With x = max_t |q_t| * max_r |k_r| / sqrt(384) -- a bound on sum_i |q_i k_i| / sqrt(384),
+// hence on every |logit|, by Cauchy-Schwarz -- one e'[t][r] of the sweep differs from the re-score's by a relative
+//   eps = x (1151 * 2u (1 + 2^-9) + 2^-22 + u)    fp32 accumulation of 1152 products inside the MFMAs (worst case, any order, 2u per
+//                                                 addition: covers a truncating as well as a round-to-nearest adder), the dropped
+//                                                 l x l term, the rounding of the exact sum to fp32                          <= 1.38e-4 x
+//       + 2 * 128 u ln2                           the fma forming the exp2 argument (|argument| <= 128 or e' is 0 / inf), both sides
+//       + 2 * 2 u                                 v_exp_f32 (1 ulp), both sides
+//       + 2 * 10 u                                the sums over the 256 tokens (trees of depth <= 10), both sides,    u = 2^-24
+// and so does U[r] (a sum of non-negative e').  A ray of the true top-k has S = sum_t e'_exact / g_t >= U_(k) / ((1 + eps) g_max) and
+// S <= U[r] / ((1 - eps) g_min):   U[r] >= U_(k) (g_min / g_max) (1 - eps) / (1 + eps).
+constexpr float kEpsPerX = 1.4e-4f, kEpsConst = 1.3e-5f;
 __global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ gsum, const int* __restrict__ n_tok, const float* __restrict__ valU,
-                                                   int topk, int k_eff, float* __restrict__ info) {
-  __shared__ float smin[4], smax[4];
+                                                   const float* __restrict__ q, const float* __restrict__ key_norm_max, int topk, int k_eff,
+                                                   float* __restrict__ info) {
+  __shared__ float smin[4], smax[4], sq[4];
   const int bl = blockIdx.x, t = threadIdx.x, M = n_tok[bl];
   const float g = gsum[(int64_t)bl * kT + t];
   float lo = t < M ? g : INFINITY, hi = t < M ? g : -INFINITY;
   bool bad = t < M && !(g > 0.f && g < INFINITY);
+  float qn = 0.f;
+  if (t < M) {
+    const float4* qr = reinterpret_cast<const float4*>(q + ((int64_t)bl * kT + t) * SIXDGS_D);
+    float ss = 0.f;
+    for (int i = 0; i < SIXDGS_D / 4; ++i) {
+      const float4 v = qr[i];
+      ss = __builtin_fmaf(v.x, v.x, ss); ss = __builtin_fmaf(v.y, v.y, ss); ss = __builtin_fmaf(v.z, v.z, ss); ss = __builtin_fmaf(v.w, v.w, ss);
+    }
+    qn = sqrtf(ss) * 1.000244140625f;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, o, 64));
     hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    qn = fmaxf(qn, __shfl_xor(qn, o, 64));
   }
   const unsigned long long anybad = __ballot(bad);
-  if (sdg_lane() == 0) { smin[sdg_wave()] = anybad ? NAN : lo; smax[sdg_wave()] = hi; }
+  if (sdg_lane() == 0) { smin[sdg_wave()] = anybad ? NAN : lo; smax[sdg_wave()] = hi; sq[sdg_wave()] = qn; }
   __syncthreads();
   if (t == 0) {
-    float flag = 0.f, thr = INFINITY;
+    float flag = 0.f, thr = INFINITY, eps = 0.f, x = 0.f;
     if (M <= 0) flag = 1.f;
     else {
-      float a = smin[0], b = smax[0];
+      float a = smin[0], b = smax[0], qm = sq[0];
       bool nan = a != a;
-      for (int w = 1; w < 4; ++w) { nan = nan || smin[w] != smin[w]; a = fminf(a, smin[w]); b = fmaxf(b, smax[w]); }
+      for (int w = 1; w < 4; ++w) { nan = nan || smin[w] != smin[w]; a = fminf(a, smin[w]); b = fmaxf(b, smax[w]); qm = fmaxf(qm, sq[w]); }
       const float uk = valU[(int64_t)bl * topk + (k_eff - 1)];
-      if (nan || !(uk >= 0.f && uk < INFINITY) || !(a > 0.f)) flag = 2.f;
-      else thr = uk * (a / b) * 0.99998474f;      // (1 - 2^-16): fp32 rounding of U (256-term sums) and of the exact re-score
+      x = qm * key_norm_max[0] * kInvSqrtD * 1.0000002f;
+      eps = x * kEpsPerX + kEpsConst;
+      if (nan || !(uk >= 0.f && uk < INFINITY) || !(a > 0.f) || !(eps < 0.25f)) flag = 2.f;
+      else thr = (uk * (a / b)) * ((1.f - eps) / (1.f + eps)) * 0.9999998f;      // the last factor: the roundings of this very line
     }
     info[bl * 4 + 0] = thr;
     info[bl * 4 + 1] = flag;
+    info[bl * 4 + 2] = eps;
+    info[bl * 4 + 3] = x;
   }
 }
 
@@ -2031,18 +2086,30 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
   return 0;
 }
 
-int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const int32_t* d_n_tok, int batch, const float* gsum, int topk,
-                             int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t rows, float* d_norm_max, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(rows >= 0);
+  if (rows == 0) return 0;
+  SDG_CHECK_ARG(planes && d_scale && d_norm_max && ((uintptr_t)planes % 16) == 0);
+  const int64_t blocks = sdg_cdiv(rows, 4);
+  hipLaunchKernelGGL(k_plane_norm_max, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, sdg_stream(stream), (const char*)planes, d_scale,
+                     rows, reinterpret_cast<unsigned*>(d_norm_max));
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
+                             const float* d_key_norm_max, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes,
+                             sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
-  SDG_CHECK_ARG(u && d_n_tok && gsum && cand && d_count && ws && ((uintptr_t)ws % 256) == 0);
+  SDG_CHECK_ARG(u && q && d_n_tok && gsum && d_key_norm_max && cand && d_count && ws && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)q % 16) == 0);
   hipStream_t s = sdg_stream(stream);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, topk, max_candidates, &w, false)) return SIXDGS_E_WORKSPACE;
   const int k_eff = (int)(r < topk ? r : topk);
   int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
   if (st) return st;
-  hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, topk, k_eff, w.info);
+  hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info);
   const dim3 cg((unsigned)w.p.nbc, (unsigned)batch);
   hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
   hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
@@ -2083,13 +2150,13 @@ size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int m
 }
 
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                        const float* d_key_scale, int64_t r, const void* sample_planes, const float* d_sample_scale, int64_t r_sample,
-                        int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
+                        const float* d_key_scale, const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale,
+                        int64_t r_sample, int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
                         sixdgs_stream_t stream, sixdgs_profile* prof) {
   SDG_CHECK_ARG(r >= 1 && r_sample >= 1 && r_sample <= r && batch >= 0 && topk >= 1 && topk <= 1024 && max_candidates >= topk &&
                 max_candidates <= (1 << 20) && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
-  SDG_CHECK_ARG(q && d_n_tok && idx && val && d_status && ws && ((uintptr_t)ws % 256) == 0);
+  SDG_CHECK_ARG(q && d_n_tok && d_key_norm_max && idx && val && d_status && ws && ((uintptr_t)ws % 256) == 0);
   int64_t bg = batch > 4096 ? 4096 : batch;
   while (bg >= 1 && sixdgs_score_select_workspace_bytes(r, (int)bg, topk, max_candidates) > ws_bytes) --bg;
   if (bg < 1) return SIXDGS_E_WORKSPACE;
@@ -2111,7 +2178,7 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
     st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, ws, stage,
                              stream, prof);
     if (st) return st;
-    st = sixdgs_select_candidates(u, (int64_t)stride, r, ng, nb, gsum, topk, max_candidates, cand, count, ws, stage, stream);
+    st = sixdgs_select_candidates(u, (int64_t)stride, r, qg, ng, nb, gsum, d_key_norm_max, topk, max_candidates, cand, count, ws, stage, stream);
     if (st) return st;
     st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates,
                                idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, stream);

@@ -23,6 +23,11 @@ from .backbone import BackboneWrapper, BatchedTokens
 from .camera_direction_network import CameraDirectionPredictor
 
 
+def _lib_ray_keys_ws(r: int, max_chunk: int = 262144) -> int:
+    from . import _lib
+    return int(_lib.load().sixdgs_ray_keys_workspace_bytes(int(r), int(max_chunk)))
+
+
 class RayPreprocessor(torch.nn.Module):
     """Parameter holder with the reference layout (ray_preprocessor.py:11-34)."""
 
@@ -139,7 +144,9 @@ class IdentificationModule(torch.nn.Module):
                 si = ops.select_sample_indices(r, rays_ori.device)
                 _, _, (s_planes, s_scale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
                 sample = (s_planes, s_scale)
-            self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale, "sample": sample}, ident
+            # max |k_r| of the scene: the select path's slack is derived from it (sixdgs.h: sixdgs_score_select); one pass over the planes
+            norm = ops.key_norm_max(planes, scale) if (planes_mode and mode in ops.F16_MODES) else None
+            self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale, "sample": sample, "norm": norm}, ident
             self._key_cache_rays = (rays_ori, rays_dir, rays_rgb)
         return self._key_cache
 
@@ -175,12 +182,15 @@ class IdentificationModule(torch.nn.Module):
                 token_list = token_list.dense()
             else:
                 wq, bq = self.attention.q_proj.weight, self.attention.q_proj.bias
-                key = (self._packed_key, token_list.pe.data_ptr())
-                if getattr(self, "_peq", None) is None or self._peq[0] != key:
-                    self._peq = (key, torch.addmm(bq.detach(), token_list.pe, wq.detach()[:, ops.D:].t()).contiguous(),
-                                 wq.detach()[:, :ops.D].contiguous())
-                q = ops.linear(token_list.feats.reshape(b * t, ops.D), self._peq[2]).view(b, t, ops.D)
-                q += self._peq[1]
+                # the cache entry HOLDS the position table it was built from (identity + in-place version, like _ensure_keys holds the
+                # rays): an address alone could be handed to another table by the allocator while the entry lives
+                pe = token_list.pe
+                c = getattr(self, "_peq", None)
+                if c is None or c[0] != self._packed_key or c[1] is not pe or c[2] != pe._version:
+                    self._peq = c = (self._packed_key, pe, pe._version, torch.addmm(bq.detach(), pe, wq.detach()[:, ops.D:].t()).contiguous(),
+                                     wq.detach()[:, :ops.D].contiguous())
+                q = ops.linear(token_list.feats.reshape(b * t, ops.D), c[4]).view(b, t, ops.D)
+                q += c[3]
                 return q, self._full_ntok(b, device), [t] * b
         if torch.is_tensor(token_list):          # pre-batched dense [B,256,398]: every image has all 256 tokens
             tokens = token_list.contiguous()
@@ -241,7 +251,8 @@ class IdentificationModule(torch.nn.Module):
                 self._select_ws = sw = None
                 self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
             idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
-                                                max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host)
+                                                max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
+                                                key_norm=kc["norm"])
             st = status.tolist()                       # the one host sync of the path (B ints)
             self.last_select_candidates = st
             redo = [i for i, v in enumerate(st) if v < 0]
@@ -260,7 +271,7 @@ class IdentificationModule(torch.nn.Module):
 
     @torch.no_grad()
     def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608,
-                              profile=None, key_cache_bytes: Optional[int] = None, return_stats: bool = False):
+                              profile=None, key_cache_bytes: Optional[int] = None, return_stats: bool = False, use_select: bool = True):
         """The scorer without a resident key cache, for ray sets whose keys (1536 B/ray) plus logits (784 B/ray/image) exceed
         the GPU: the rays go through in chunks, ALL images of the batch share each chunk's keys, and the keys are computed,
         used and dropped -- twice, because the softmax runs over ALL rays: sweep 1 collects each chunk's row statistics and
@@ -278,7 +289,7 @@ class IdentificationModule(torch.nn.Module):
         mode = ops.effective_mma_mode()
         f16, planes_mode = mode in ops.F16_MODES, mode != ops.MMA_F32
         self.last_scoring_path = "streamed two-pass"
-        if (f16 and not return_stats and ops.select_enabled() and r >= ops.SELECT_MIN_RAYS and k <= ops.SELECT_MAX_CANDIDATES
+        if (f16 and use_select and not return_stats and ops.select_enabled() and r >= ops.SELECT_MIN_RAYS and k <= ops.SELECT_MAX_CANDIDATES
                 and not torch.cuda.is_current_stream_capturing()):
             # Select path, streamed: ONE sweep of ray MLP + matrix-core pass over the chunks (plus 1/16 for the sample) instead
             # of two -- U (4 B per ray and image) is all that is kept of a chunk; the candidates' keys are recomputed at the end.
@@ -308,18 +319,18 @@ class IdentificationModule(torch.nn.Module):
             self.last_scoring_path = "streamed select" if not redo else f"streamed select+two-pass({len(redo)})"
             if redo:
                 del ss
-                ops.set_select_enabled(False)
-                try:
-                    sub = token_list[torch.tensor(redo, device=dev)] if (torch.is_tensor(token_list) or isinstance(token_list, BatchedTokens)) else [token_list[i] for i in redo]
-                    i2, v2 = self.score_tokens_streamed(sub, rays_ori, rays_dir, rays_rgb, k, chunk_rays, profile, key_cache_bytes)
-                finally:
-                    ops.set_select_enabled(True)
+                sub = token_list[torch.tensor(redo, device=dev)] if (torch.is_tensor(token_list) or isinstance(token_list, BatchedTokens)) else [token_list[i] for i in redo]
+                i2, v2 = self.score_tokens_streamed(sub, rays_ori, rays_dir, rays_rgb, k, chunk_rays, profile, key_cache_bytes, use_select=False)
                 sel = torch.tensor(redo, device=dev)
                 idx[sel], val[sel] = i2, v2
             return idx, val
         ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), dtype=torch.uint8, device=dev)
         if key_cache_bytes is None:
-            key_cache_bytes = int(0.7 * torch.cuda.mem_get_info(dev)[0])
+            # 70 % of what is free once the transient needs of ONE chunk are set aside: its key planes (they exist while the chunk is
+            # scored, kept or not) and the ray-MLP workspace of sixdgs_ray_keys_ex
+            n_c = min(chunk, r)
+            transient = n_c * (1536 if f16 else (2304 if planes_mode else 4 * ops.D)) + int(_lib_ray_keys_ws(n_c))
+            key_cache_bytes = max(0, int(0.7 * (torch.cuda.mem_get_info(dev)[0] - transient)))
         kept, kept_bytes = {}, 0                                                  # r0 -> key operand of the chunk, sweep 1 -> sweep 2
 
         def chunk_keys(r0, may_keep):

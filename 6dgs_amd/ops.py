@@ -4,6 +4,8 @@ library does the work.  Every function requires CUDA(ROCm) tensors -- there is n
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -42,19 +44,59 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-_call_device = None      # device of the tensors of the call being marshalled (set by _need_gpu, read by _stream)
+_tls = threading.local()     # .device: index of the device of the call being marshalled on this thread (set by _on_device / _need_gpu)
 
 
 def _stream():
     """The current PyTorch stream OF THE TENSORS' DEVICE (not of whatever device is current in the process)."""
-    dev = _call_device if _call_device is not None else torch.cuda.current_device()
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    dev = getattr(_tls, "device", None)
+    return C.c_void_p(torch.cuda.current_stream(dev if dev is not None else torch.cuda.current_device()).cuda_stream)
+
+
+def _first_device(objs):
+    for a in objs:
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (PackedWeights, SelectStream)):
+            if getattr(a, "device", None) is not None:      # None while the object is being constructed
+                return a.device
+        elif isinstance(a, (list, tuple)) and a and torch.is_tensor(a[0]) and a[0].is_cuda:
+            return a[0].device
+        elif isinstance(a, (str, torch.device)) and not isinstance(a, bool):
+            try:
+                d = torch.device(a)
+            except (RuntimeError, TypeError, ValueError):
+                continue
+            if d.type == "cuda":
+                return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+    return None
+
+
+def _on_device(fn):
+    """Every library call runs with the device of its tensor arguments current -- the kernels launch on the device that is current
+    when the library is entered -- and puts the process's current device back afterwards (a call on cuda:1 tensors does not move
+    the caller to cuda:1).  The device is kept per THREAD for _stream(), so concurrent callers on different devices do not see each
+    other's choice."""
+    @functools.wraps(fn)
+    def scoped(*args, **kwargs):
+        dev = _first_device(list(args) + list(kwargs.values()))
+        prev = getattr(_tls, "device", None)
+        try:
+            if dev is None or not torch.cuda.is_available():
+                return fn(*args, **kwargs)
+            _tls.device = dev.index
+            if dev.index == torch.cuda.current_device():
+                return fn(*args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+        finally:
+            _tls.device = prev
+    return scoped
 
 
 def _need_gpu(*ts):
-    """Every tensor argument must be a GPU tensor, all on ONE device; that device is made current for the launch (the
-    kernels run on the device that is current when the library is entered) and its current stream is the one passed."""
-    global _call_device
+    """Every tensor argument must be a GPU tensor, all on ONE device -- the device _on_device made current for the call."""
     dev = None
     for t in ts:
         if t is None:
@@ -66,9 +108,7 @@ def _need_gpu(*ts):
         elif t.device != dev:
             raise RuntimeError(f"6dgs_amd: tensor arguments on different devices ({dev} and {t.device})")
     if dev is not None:
-        _call_device = dev.index
-        if torch.cuda.current_device() != dev.index:
-            torch.cuda.set_device(dev)
+        _tls.device = dev.index
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -85,6 +125,7 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # geometry
 # ---------------------------------------------------------------------------------------------
+@_on_device
 def mask_degraded(log_scale: torch.Tensor, target_points: int = 50) -> torch.Tensor:
     log_scale = _f32(log_scale)
     _need_gpu(log_scale)
@@ -94,6 +135,7 @@ def mask_degraded(log_scale: torch.Tensor, target_points: int = 50) -> torch.Ten
     return out.bool()
 
 
+@_on_device
 def sym_eig_3x3(mats: torch.Tensor, eigenvectors: bool = True):
     mats = _f32(mats)
     _need_gpu(mats)
@@ -108,6 +150,7 @@ def sym_eig_3x3(mats: torch.Tensor, eigenvectors: bool = True):
 KNN_GRID_FROM = 16384     # clouds at least this large take the grid search (identical results, O(E) instead of O(E^2))
 
 
+@_on_device
 def normals_knn(query: torch.Tensor, cloud: torch.Tensor, k: int = 20, return_knn: bool = False, method: str = "auto"):
     """a4.  method: "brute" (the reference's exhaustive search), "grid" (uniform-grid search, same neighbour lists and
     normals bit for bit) or "auto" (grid from KNN_GRID_FROM points)."""
@@ -131,6 +174,7 @@ def normals_knn(query: torch.Tensor, cloud: torch.Tensor, k: int = 20, return_kn
     return (out, knn) if return_knn else out
 
 
+@_on_device
 def quadricell_centers(scale: torch.Tensor, target_points: int = 50, table_res: int = 1000):
     """a6 alone: (points[C,3], ellipsoid_id[C]) for activated semi axes scale[E,3]."""
     scale = _f32(scale)
@@ -152,6 +196,7 @@ def quadricell_centers(scale: torch.Tensor, target_points: int = 50, table_res: 
     return pts, eid
 
 
+@_on_device
 def emit_quadricell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel: Optional[torch.Tensor], normals, target_points: int = 50,
                     table_res: int = 1000, scale_is_log: bool = True, want_rgb: bool = True):
     """a1+a6+a7+a10: returns ori[R,3], dir[R,3], rgb[R,3] (or None), src[R] (Gaussian id), n_cells."""
@@ -187,6 +232,7 @@ def emit_quadricell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel: Optional
     return ori, dr, rgb, src, n_cells
 
 
+@_on_device
 def isocell_distribution(ray_target: int, n0: int = 1, device="cuda") -> torch.Tensor:
     lib = _lib.load()
     cnt = C.c_int64(0)
@@ -197,6 +243,7 @@ def isocell_distribution(ray_target: int, n0: int = 1, device="cuda") -> torch.T
     return out
 
 
+@_on_device
 def rotate_isocell(dirs: torch.Tensor, normals: torch.Tensor) -> torch.Tensor:
     dirs, normals = _f32(dirs), _f32(normals)
     _need_gpu(dirs, normals)
@@ -206,6 +253,7 @@ def rotate_isocell(dirs: torch.Tensor, normals: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def emit_isocell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel, normals, dirs, scale_is_log: bool = True,
                  want_rgb: bool = True, want_src: bool = True):
     xyz, scale, rot, normals, dirs = _f32(xyz), _f32(scale), _f32(rot), _f32(normals), _f32(dirs)
@@ -228,6 +276,7 @@ def emit_isocell(xyz, scale, rot, f_dc, f_rest, sh_degree: int, sel, normals, di
     return ori, dr, rgb, src
 
 
+@_on_device
 def eval_sh_color(sh: torch.Tensor, dirs: torch.Tensor, sh_degree: int) -> torch.Tensor:
     sh, dirs = _f32(sh), _f32(dirs)
     _need_gpu(sh, dirs)
@@ -246,6 +295,7 @@ class PackedWeights:
     KEYS = ("ray_preprocessor.mlp.0", "ray_preprocessor.mlp.2", "ray_preprocessor.mlp2.0", "ray_preprocessor.mlp2.2",
             "attention.k_proj", "attention.q_proj")
 
+    @_on_device
     def __init__(self, state_dict, device):
         lib = _lib.load()
         srcs = []
@@ -254,6 +304,7 @@ class PackedWeights:
             srcs.append(_f32(state_dict[k + ".bias"]).to(device))
         self._srcs = srcs
         self.buffer = torch.empty(lib.sixdgs_packed_weights_floats(), device=device)
+        self.device = self.buffer.device
         self.struct = ScorerWeights()
         check(lib.sixdgs_pack_weights(*[_p(t) for t in srcs], _p(self.buffer), C.byref(self.struct), _stream()), "pack_weights")
 
@@ -280,6 +331,7 @@ class KernelProfile:
         return ms.value, fl.value, by.value, n.value
 
 
+@_on_device
 def ray_encode(ori, dr, rgb) -> torch.Tensor:
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
@@ -288,6 +340,7 @@ def ray_encode(ori, dr, rgb) -> torch.Tensor:
     return x
 
 
+@_on_device
 def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, split_k: Optional[int] = None) -> torch.Tensor:
     """y = x w^T + b (optionally ReLU).  split_k: None = automatic (K is cut into slices computed by separate workgroups when
     the output has too few 128x128 tiles to fill the 256 CUs and K is long), 1 = never, n = that many slices."""
@@ -311,6 +364,7 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
     return y
 
 
+@_on_device
 def split_planes(x: torch.Tensor) -> torch.Tensor:
     """fp32 [rows,384] -> bf16 planes as uint8 [rows, 2304] ([12 slabs][3 planes][32 k] per row)."""
     x = _f32(x)
@@ -320,6 +374,7 @@ def split_planes(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def split_planes_f16(x: torch.Tensor):
     """fp32 [rows,384] -> (scaled fp16 planes as uint8 [rows,1536], reciprocal power-of-two scale of every 128-row tile)."""
     x = _f32(x)
@@ -330,6 +385,7 @@ def split_planes_f16(x: torch.Tensor):
     return out, scale
 
 
+@_on_device
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
              workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False):
     """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes) where planes is uint8 [R,2304]
@@ -354,6 +410,7 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     return feat, key
 
 
+@_on_device
 def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """list of [T_i, 398] -> tokens [B,256,398] (zero padded), n_tok int32 [B] (device)."""
     b = len(token_list)
@@ -367,6 +424,7 @@ def pad_tokens(token_list, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return tok, n.to(device)
 
 
+@_on_device
 def q_proj(tokens: torch.Tensor, n_tok: torch.Tensor, weights: PackedWeights) -> torch.Tensor:
     tokens = _f32(tokens)
     _need_gpu(tokens, n_tok)
@@ -384,6 +442,7 @@ def score_topk_workspace_bytes(r: int, batch: int, topk: int = 100, planes: bool
     return int(_lib.load().sixdgs_score_topk_workspace_bytes(int(r), int(batch), int(topk)))
 
 
+@_on_device
 def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], topk: int = 100, want_scores: bool = True,
                want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
                profile: Optional["KernelProfile"] = None, n_tok_host=None, key_planes: Optional[torch.Tensor] = None,
@@ -435,6 +494,7 @@ def select_enabled() -> bool:
     return _select_enabled
 
 
+@_on_device
 def select_sample_indices(r: int, device, stride: Optional[int] = None) -> torch.Tensor:
     """One ray of every `stride` consecutive ones (default: 16, or 32 from SELECT_LARGE_RAYS rays), at a position that varies
     pseudo-randomly from group to group (a fixed position would pick the same iso-cell direction of every ellipsoid):
@@ -446,17 +506,35 @@ def select_sample_indices(r: int, device, stride: Optional[int] = None) -> torch
     return i * stride + (((i * 2654435761) & 0xFFFFFFFF) >> 13) % stride
 
 
+@_on_device
+def key_norm_max(planes: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max_r |k_r| of the rows of scaled fp16 key planes as a device scalar [1] (rounded up: the select path's error bound is built
+    on it, include/sixdgs.h).  `out`: accumulate into an existing scalar (scenes that go through in chunks)."""
+    _need_gpu(planes, scale, out)
+    if planes.shape[1] != 1536:
+        raise RuntimeError("6dgs_amd: key_norm_max needs scaled fp16 key planes (MMA_F16X3)")
+    if out is None:
+        out = torch.zeros(1, device=planes.device)
+    check(_lib.load().sixdgs_key_planes_norm_max(_p(planes), _p(scale), planes.shape[0], _p(out), _stream()), "key_planes_norm_max")
+    return out
+
+
 def score_select_workspace_bytes(r: int, batch: int, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES) -> int:
     return int(_lib.load().sixdgs_score_select_workspace_bytes(int(r), int(batch), int(topk), int(max_candidates)))
 
 
+@_on_device
 def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
                  sample_scale: torch.Tensor, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
-                 workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, n_tok_host=None):
+                 workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, n_tok_host=None,
+                 key_norm: Optional[torch.Tensor] = None):
     """Top-k without materialised logits (include/sixdgs.h: sixdgs_score_select).  Returns (idx [B,k], val [B,k], status [B] int32 on
-    the device: candidates examined, or -1 = this image needs the two-pass scorer)."""
+    the device: candidates examined, or -1 = this image needs the two-pass scorer).  key_norm: key_norm_max(key_planes, key_scale),
+    computed here (one more pass over the planes) when not handed in -- callers with a key cache keep it beside the planes."""
     q = _f32(q)
-    _need_gpu(q, n_tok, key_planes, key_scale, sample_planes, sample_scale)
+    _need_gpu(q, n_tok, key_planes, key_scale, sample_planes, sample_scale, key_norm)
+    if key_norm is None:
+        key_norm = key_norm_max(key_planes, key_scale)
     if key_planes.shape[1] != 1536 or sample_planes.shape[1] != 1536:
         raise RuntimeError("6dgs_amd: score_select needs scaled fp16 key planes (MMA_F16X3)")
     lib = _lib.load()
@@ -467,7 +545,7 @@ def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor,
     if workspace is None:
         workspace = torch.empty(score_select_workspace_bytes(r, b, topk, max_candidates), dtype=torch.uint8, device=dev)
     h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if (profile is not None and n_tok_host is not None) else None
-    check(lib.sixdgs_score_select(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), r, _p(sample_planes), _p(sample_scale), rs,
+    check(lib.sixdgs_score_select(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), _p(key_norm), r, _p(sample_planes), _p(sample_scale), rs,
                                   int(topk), int(max_candidates), _p(idx), _p(val), _p(status), _p(workspace), workspace.numel(), _stream(),
                                   profile.ref if profile is not None else None), "score_select")
     return idx, val, status
@@ -478,16 +556,19 @@ class SelectStream:
     go through in chunks: begin(sample planes) -> sweep(chunk planes, ray offset) per chunk -> candidates() -> rescore(planes of
     the candidates).  Holds the caller-side buffers: ctok, gsum [B,256], U [B, R rounded up to 256]."""
 
+    @_on_device
     def __init__(self, q: torch.Tensor, n_tok: torch.Tensor, r_total: int, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
                  n_tok_host=None):
         self.q, self.n_tok = _f32(q), n_tok
         _need_gpu(self.q, n_tok)
         self.b, self.dev = self.q.shape[0], self.q.device
+        self.device = self.dev
         self.r, self.topk, self.cmax = int(r_total), int(topk), int(max_candidates)
         self.stride = (self.r + 255) // 256 * 256
         self.ctok = torch.empty(self.b, MAX_TOKENS, device=self.dev)
         self.gsum = torch.empty(self.b, MAX_TOKENS, device=self.dev)
         self.u = torch.empty(self.b, self.stride, device=self.dev)
+        self.key_norm = torch.zeros(1, device=self.dev)        # max |k_r| over the chunks swept so far (the bound of the candidate stage)
         self.ws = torch.empty(1, dtype=torch.uint8, device=self.dev)
         self.h_n = (C.c_int32 * self.b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
 
@@ -496,6 +577,7 @@ class SelectStream:
             self.ws = None
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
 
+    @_on_device
     def begin(self, sample_planes, sample_scale):
         _need_gpu(self.q, sample_planes, sample_scale)
         lib = _lib.load()
@@ -503,6 +585,7 @@ class SelectStream:
         check(lib.sixdgs_select_begin(_p(self.q), _p(self.n_tok), self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0], self.r,
                                       _p(self.ctok), _p(self.gsum), _p(self.ws), self.ws.numel(), _stream()), "select_begin")
 
+    @_on_device
     def sweep(self, planes, scale, ray_offset: int, profile: Optional["KernelProfile"] = None):
         if ray_offset % 256:
             raise RuntimeError("6dgs_amd: select sweep chunks must start at a multiple of 256 rays")
@@ -513,7 +596,9 @@ class SelectStream:
         check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n if profile is not None else None, self.b, _p(planes), _p(scale), rc,
                                       _p(self.ctok), _p(self.gsum), C.c_void_p(self.u.data_ptr() + 4 * int(ray_offset)), self.stride,
                                       _p(self.ws), self.ws.numel(), _stream(), profile.ref if profile is not None else None), "select_sweep")
+        key_norm_max(planes, scale, out=self.key_norm)
 
+    @_on_device
     def candidates(self):
         """-> (cand [B,cmax] int64 ascending ray indices, count [B] int32 on the device)"""
         lib = _lib.load()
@@ -521,10 +606,11 @@ class SelectStream:
         self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
         cand = torch.zeros(self.b, self.cmax, dtype=torch.int64, device=self.dev)
         count = torch.empty(self.b, dtype=torch.int32, device=self.dev)
-        check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.n_tok), self.b, _p(self.gsum), self.topk, self.cmax,
-                                           _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
+        check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.q), _p(self.n_tok), self.b, _p(self.gsum), _p(self.key_norm),
+                                           self.topk, self.cmax, _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
         return cand, count
 
+    @_on_device
     def rescore(self, planes, scale, cand, count, compact: bool):
         """-> (idx [B,k], val [B,k], status [B] int32)"""
         lib = _lib.load()
@@ -539,6 +625,7 @@ class SelectStream:
         return idx, val, status
 
 
+@_on_device
 def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor], workspace: torch.Tensor, topk: int = 100,
                 key_planes: Optional[torch.Tensor] = None, key_scale: Optional[torch.Tensor] = None,
                 profile: Optional["KernelProfile"] = None, n_tok_host=None) -> torch.Tensor:
@@ -557,6 +644,7 @@ def score_pass1(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor
     return stats
 
 
+@_on_device
 def score_pass2(stats: torch.Tensor, n_tok: torch.Tensor, r: int, workspace: torch.Tensor, topk: int = 100, used_planes: bool = True,
                 want_scores: bool = True):
     """Second half: global row statistics [B,256,2] -> (local idx [B,k], val [B,k], scores [B,r] | None) of this shard."""
@@ -571,6 +659,7 @@ def score_pass2(stats: torch.Tensor, n_tok: torch.Tensor, r: int, workspace: tor
     return idx, val, scores
 
 
+@_on_device
 def topk(scores: torch.Tensor, k: int = 100):
     scores = _f32(scores)
     _need_gpu(scores)
@@ -587,6 +676,7 @@ def topk(scores: torch.Tensor, k: int = 100):
 # ---------------------------------------------------------------------------------------------
 # DistanceBasedScoreLoss target scores
 # ---------------------------------------------------------------------------------------------
+@_on_device
 def distance_target(rays_ori, rays_dir, pose, n_tokens: int, want_sum: bool = False):
     """Target scores [R] of distance_based_loss.py for the ground-truth c2w `pose` [4,4] (any device), summing to n_tokens."""
     rays_ori, rays_dir = _f32(rays_ori), _f32(rays_dir)
@@ -605,6 +695,7 @@ def distance_target(rays_ori, rays_dir, pose, n_tokens: int, want_sum: bool = Fa
 # ---------------------------------------------------------------------------------------------
 # pose
 # ---------------------------------------------------------------------------------------------
+@_on_device
 def solve_pose(rays_ori, rays_dir, idx, val, up, gt_c2w=None):
     """Batched pose tail.  idx/val [B,k], up [B,3], gt_c2w [B,4,4] or None.
     Returns dict(c2w[B,4,4], status[B], w_final[B,k], n_kept[B], centre[B,3], errors[B,2])."""

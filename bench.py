@@ -319,8 +319,10 @@ def main():
     }
     if streamed:
         out["config"]["chunk_rays"] = args.chunk_rays
-        out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj "
-                                         "and the scorer twice (row statistics, then scores + top-k merge); nothing of size R x 384 is resident")
+        out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj and the scorer "
+                                         + ("ONCE (select path: U of every ray kept, 4 B per ray and image; the candidates' keys are recomputed and re-scored exactly)"
+                                            if path.startswith("streamed select") else "twice (row statistics, then scores + top-k merge)")
+                                         + "; nothing of size R x 384 is resident")
     out["config"]["scoring_path"] = path
     if cand is not None:
         out["config"]["select_candidates_last_batch"] = cand

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 3   /* 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -277,13 +277,19 @@ int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch
  *   main sweep  over all rays, one matrix-core pass, nothing of size T x R leaves the chip: U[r] = sum_t e[t][r] / (f Z~_t)
  *               (4 x 4 B per ray and image instead of 784 B of logits) and the EXACT g_t = Z_t / (f Z~_t);
  *   bounds      score[r] = sum_t e'[t][r] / g_t lies in [U[r] / g_max, U[r] / g_min], so every ray of the true top-k has
- *               U[r] >= U_(k) g_min / g_max (U_(k) = k-th largest U);
+ *               U[r] >= U_(k) g_min / g_max (1 - eps) / (1 + eps) (U_(k) = k-th largest U).  eps bounds the relative difference between
+ *               the sweep's U and the exact re-score: eps = 1.4e-4 x + 1.3e-5 with x = max_t |q_t| max_r |k_r| / sqrt(384) >= every
+ *               sum_i |q_i k_i| / sqrt(384) (fp32 accumulation of 1152 products in the MFMAs + the epilogue's roundings; derivation at
+ *               k_sel_bounds).  d_key_norm_max (device scalar): max_r |k_r| of the scene, from sixdgs_key_planes_norm_max;
  *   re-score    those candidates exactly (fp32, from their key planes and the exact g_t); their top-k (value descending, ties ->
  *               lowest index) is the result.  The sample decides only how many candidates there are, never the answer.
  * d_status[b] (device) = number of candidates examined, or -1 when this image must be scored by sixdgs_score_topk_ex instead
  * (more than max_candidates candidates, or an exponent overflow because a logit exceeds the sample maximum by > 88).
  * max_candidates: multiple of 8, >= topk.  Workspace ~ 20 B per ray and image. */
 size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);
+/* *d_norm_max = max(*d_norm_max, max over the rows of |x_row|) for the values the scaled fp16 planes hold (rounded up: it is used as a
+ * bound).  Zero *d_norm_max before the first call; scenes that go through in chunks accumulate chunk by chunk. */
+int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t rows, float* d_norm_max, sixdgs_stream_t stream);
 /* The four stages of the select path as entry points of their own, for scenes whose key planes do not fit the GPU: `begin` once
  * (sample pre-pass), `sweep` per ray chunk (chunks start at multiples of 256 rays; each writes its columns of U and adds its
  * share of the exact per-token sums into gsum), `candidates` once over the whole U, then `rescore` on the key planes of the
@@ -300,14 +306,15 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
                         const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
                         size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
-int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const int32_t* d_n_tok, int batch, const float* gsum, int topk,
-                             int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
+                             const float* d_key_norm_max, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes,
+                             sixdgs_stream_t stream);
 int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
                           const float* ctok, const float* gsum, const int64_t* cand, const int32_t* d_count, int64_t r, int topk,
                           int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy for the FLOP count, may be NULL*/,
-                        int batch, const void* key_planes, const float* d_key_scale, int64_t r, const void* sample_planes,
-                        const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,
+                        int batch, const void* key_planes, const float* d_key_scale, const float* d_key_norm_max, int64_t r,
+                        const void* sample_planes, const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,
                         float* val /*[B,topk]*/, int32_t* d_status /*[B]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
                         sixdgs_profile* prof);
 /* top-k alone over precomputed scores [B,R] */

@@ -180,3 +180,95 @@ def test_select_stage_by_stage_over_chunks_matches_the_resident_call(ops):
     i3, v3, st3 = ss.rescore(c["planes"], c["scale"], cand, count, compact=False)
     for b in range(3):
         assert torch.equal(i3[b], idx[b]) and float((v3[b] - val[b]).abs().max() / val[b][0]) < 1e-6
+
+
+def _exact_scores(q, nt, key):
+    """fp64 softmax-over-rays column sums of the fp32 operands (the quantity every scorer approximates), on the GPU."""
+    out = []
+    for b in range(q.shape[0]):
+        t = int(nt[b])
+        logits = (q[b, :t].double() @ key.double().T) / (384.0 ** 0.5)
+        out.append(torch.softmax(logits, dim=-1).sum(0))
+    return out
+
+
+def test_key_norm_max_bounds_every_row_norm_tightly(ops):
+    c = make_case(ops, 300_001, 8, 1.0, (256,), key_spread=0.7)
+    n = ops.key_norm_max(c["planes"], c["scale"])
+    true = float(c["key"].double().norm(dim=1).max())
+    assert true <= float(n) <= true * 1.0005                                       # an upper bound, within the stated rounding-up
+    acc = torch.zeros(1, device="cuda")                                              # chunk by chunk into one scalar
+    for r0 in range(0, 300_001, 100_096):
+        p, s = ops.split_planes_f16(c["key"][r0:r0 + 100_096].contiguous())
+        ops.key_norm_max(p, s, out=acc)
+    assert abs(float(acc) - float(n)) <= 1e-6 * float(n)
+
+
+def test_select_slack_follows_the_logit_error_bound_single_token_large_logits(ops):
+    """VERDICT r2 #9 / ADVICE r2: with ONE token g_min = g_max and the derived slack (1 - eps) / (1 + eps), eps = 1.4e-4 x + 1.3e-5,
+    x = |q| max|k| / sqrt(384), is all that separates the candidates from the rest.  Logits up to ~80 (x ~ 300): the sweep's U is
+    then off the exact value by up to ~1e-3 relative -- far beyond the old constant 2^-16 -- and the answer must still be the exact
+    top-100 (or a refusal, never a wrong set)."""
+    r = 1_200_000
+    g = torch.Generator(device="cpu").manual_seed(77)
+    key = (torch.randn(r, 384, generator=g) * 0.07).cuda()
+    q = torch.zeros(2, 256, 384)
+    q[:, 0] = torch.randn(2, 384, generator=g) * torch.tensor([[230.0], [120.0]])
+    q = q.cuda()
+    nt = torch.tensor([1, 1], dtype=torch.int32).cuda()
+    planes, scale = ops.split_planes_f16(key)
+    si = ops.select_sample_indices(r, "cuda")
+    sp, ss = ops.split_planes_f16(key[si].contiguous())
+    idx, val, status = ops.score_select(q, nt, planes, scale, sp, ss, 100)
+    exact = _exact_scores(q, nt, key)
+    for b in range(2):
+        lmax = float(((q[b, 0].double() @ key.double().T) / 384.0 ** 0.5).max())
+        assert lmax > (60.0 if b == 0 else 30.0)
+        st = int(status[b])
+        if st < 0:
+            assert int(idx[b].max()) == -1
+            continue
+        s = exact[b]
+        order = torch.argsort(s, descending=True, stable=True)
+        # an fp32-operand logit carries ~1e-7 x of rounding however it is summed: two rays closer than that (relative, as e^dx) are a tie
+        x = float(q[b, 0].double().norm() * key.double().norm(dim=1).max() / 384.0 ** 0.5)
+        tie = 4e-7 * x
+        must = order[:100][(s[order[:100]] / s[order[100]] - 1.0) > tie]
+        got = set(idx[b].tolist())
+        assert set(must.tolist()) <= got and len(got) == 100
+        assert float(s[idx[b]].min()) >= float(s[order[99]]) * (1.0 - tie)
+        assert float(((val[b].double() - s[idx[b]]).abs() / s[idx[b]]).max()) < max(2e-6, 2e-7 * x)
+        assert st >= 100
+
+
+def test_select_near_ties_at_the_threshold_with_large_logits(ops):
+    """Rays planted a hair below and above the 100th score (copies of the rays ranked 90..110 whose keys are scaled by 1 +- j 2e-7,
+    i.e. logits moved by ~1e-5 at |logit| ~ 30) under large logits: every ray whose exact score clears the 100th by more than the fp32
+    logit noise must be returned, nothing below it by more than that may be; the candidate set has to contain all of them."""
+    r = 1_200_000
+    c = make_case(ops, r, 31, 45.0, (256, 64))
+    key = c["key"].clone()
+    s0 = _exact_scores(c["q"], c["nt"], key)[0]
+    order = torch.argsort(s0, descending=True)
+    src = order[90:110]
+    dst = torch.arange(700_000, 700_000 + 400, device="cuda")
+    dst = dst[~torch.isin(dst, order[:200])]
+    fac = 1.0 + (torch.arange(dst.numel(), device="cuda").float() - dst.numel() / 2) * 2e-7
+    key[dst] = key[src[torch.arange(dst.numel(), device="cuda") % 20]] * fac[:, None]
+    planes, scale = ops.split_planes_f16(key)
+    si = ops.select_sample_indices(r, "cuda")
+    sp, ss = ops.split_planes_f16(key[si].contiguous())
+    idx, val, status = ops.score_select(c["q"], c["nt"], planes, scale, sp, ss, 100)
+    i2, v2, sc, _ = ops.score_topk(c["q"], c["nt"], None, 100, key_planes=planes, key_scale=scale, want_scores=True)
+    exact = _exact_scores(c["q"], c["nt"], key)
+    for b in range(2):
+        assert int(status[b]) >= 100, status.tolist()
+        s = exact[b]
+        o = torch.argsort(s, descending=True, stable=True)
+        tie = 3e-5                                   # q_scale 45: fp32 dot-product rounding x e^x (the tolerance of the 'peaked' case above)
+        must = o[:100][(s[o[:100]] / s[o[100]] - 1.0) > tie]
+        got = set(idx[b].tolist())
+        assert set(must.tolist()) <= got and len(got) == 100
+        assert float(s[idx[b]].min()) >= float(s[o[99]]) * (1.0 - tie)
+        assert float(((val[b].double() - s[idx[b]]).abs() / s[o[0]]).max()) < tie
+        assert float((val[b] - sc[b][idx[b]]).abs().max() / v2[b][0]) < tie          # and the two-pass scorer agrees on those rays
