@@ -86,8 +86,9 @@ def parse():
                     help="score with the two-pass scorer (logits through HBM) instead of the select path (top-k without materialised logits)")
     ap.add_argument("--l32-steps", type=int, default=-1,
                     help="steps of the secondary fp32-logits measurement (-1 = min(steps, 3) when the main mode is f16x3; 0 = skip)")
-    ap.add_argument("--cpu-sample-rays", type=int, default=1 << 20,
-                    help="rays of the CPU-oracle sample (also the sample of parity_vs_oracle; 2^20 = the smallest scene the select path takes)")
+    ap.add_argument("--cpu-sample-rays", type=int, default=1 << 22,
+                    help="rays of the CPU-oracle sample (also the sample of parity_vs_oracle; the select path takes scenes from 2^20 rays): 2^22 = ~10 s of "
+                         "oracle time on the 128-core host + as much for the PyTorch-CPU figure")
     ap.add_argument("--skip-reference-mode", action="store_true", help="skip the secondary reference-mode figure (1000-ellipsoid quadricell emission)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))

@@ -467,7 +467,7 @@ def test_cfg5_stand_in_sweep_of_twelve_scenes_one_rank_and_two(pkg, syn, tmp_pat
     one, two = outs
     scenes = []
     for r in one:
-        if not scenes or scenes[-1][:2] != (r["category_name"], r["sequence_id"]):
+        if not scenes or tuple(scenes[-1][:2]) != (r["category_name"], r["sequence_id"]):
             scenes.append([r["category_name"], r["sequence_id"], 0])
         scenes[-1][2] += 1
     assert [tuple(s[:2]) for s in scenes] == [e[:2] for e in sorted(expect)], scenes            # 12 scenes, directory order; the broken one is absent
