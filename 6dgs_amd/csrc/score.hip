@@ -1561,13 +1561,14 @@ __global__ void __launch_bounds__(kT) k_sel_rescore(const char* __restrict__ qp,
 // result: top-k of the exact candidate scores mapped back to ray indices; status[b] = candidates examined, or -1 when the
 // select path cannot answer for this image (bounds unusable, more than cmax candidates, fewer than k) -- the caller falls back.
 __global__ void __launch_bounds__(1024) k_sel_emit(const int64_t* __restrict__ lidx, const float* __restrict__ lval, const int64_t* __restrict__ cand,
-                                                   const int* __restrict__ count, int cmax, int topk, int k_eff, int64_t* __restrict__ idx,
-                                                   float* __restrict__ val, int* __restrict__ status) {
+                                                   const int* __restrict__ count, int cmax, int topk, int k_eff, int allow_fewer,
+                                                   int64_t* __restrict__ idx, float* __restrict__ val, int* __restrict__ status) {
   const int bl = blockIdx.x, j = threadIdx.x;
   const int n = count[bl];
   int st = n;
   if (n == -2) st = 0;
-  else if (n < 0 || n > cmax || n < k_eff) st = -1;
+  else if (n < 0 || n > cmax || (n < k_eff && !allow_fewer)) st = -1;      // a shard of a ray-sharded scene may hold fewer than k candidates
+  if (allow_fewer && n >= 0 && n < k_eff) k_eff = n;
   if (j == 0) status[bl] = st;
   if (j >= topk) return;
   if (n == -2) {                           // no tokens: every score is exactly 0 and the k lowest indices win
@@ -2037,11 +2038,11 @@ size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, 
   return p.topk_bytes + (size_t)batch * p.per_image;
 }
 
-int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
-                        int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1 && r_total >= r_sample);
+int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+                               int64_t r_sample, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1);
   if (batch == 0) return 0;
-  SDG_CHECK_ARG(q && d_n_tok && sample_planes && d_sample_scale && ctok && gsum && ws && ((uintptr_t)sample_planes % 16) == 0 &&
+  SDG_CHECK_ARG(q && d_n_tok && sample_planes && d_sample_scale && row_stats && ws && ((uintptr_t)sample_planes % 16) == 0 &&
                 ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
   hipStream_t s = sdg_stream(stream);
   SelectWs w;
@@ -2049,12 +2050,34 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const
   select_q_planes(q, batch, w, s);
   const LogitsF16Args V = select_args(d_n_tok, batch, w, sample_planes, d_sample_scale, r_sample);
   hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * batch)), dim3(512), 0, s, V);
-  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, w.stats);
-  hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, d_n_tok, 0, log2f((float)((double)r_total / (double)r_sample)), ctok);
+  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, row_stats);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_select_prepare(const float* row_stats, const int32_t* d_n_tok, int batch, int64_t r_sample, int64_t r_total, float* ctok, float* gsum,
+                          sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1 && r_total >= r_sample);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(row_stats && d_n_tok && ctok && gsum);
+  hipStream_t s = sdg_stream(stream);
+  hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)batch), dim3(kT), 0, s, row_stats, d_n_tok, 0, log2f((float)((double)r_total / (double)r_sample)), ctok);
   hipError_t e = hipMemsetAsync(gsum, 0, (size_t)batch * kT * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   SDG_LAUNCH_OK();
   return 0;
+}
+
+int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+                        int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1 && r_total >= r_sample);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0);
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, r_sample, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
+  const int st = sixdgs_select_sample_stats(q, d_n_tok, batch, sample_planes, d_sample_scale, r_sample, w.stats, ws, ws_bytes, stream);
+  if (st) return st;
+  return sixdgs_select_prepare(w.stats, d_n_tok, batch, r_sample, r_total, ctok, gsum, stream);
 }
 
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
@@ -2097,9 +2120,19 @@ int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t
   return 0;
 }
 
+int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, int batch, int topk, float* val, void* ws, size_t ws_bytes,
+                         sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(u && val && ws && ((uintptr_t)ws % 256) == 0);
+  SelectWs w;
+  if (!select_ws(ws, ws_bytes, r, batch, topk, 8, &w, false)) return SIXDGS_E_WORKSPACE;
+  return run_topk(u, u_stride, r, batch, topk, w.idxU, val, w.topk_ws, sdg_stream(stream));
+}
+
 int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
-                             const float* d_key_norm_max, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes,
-                             sixdgs_stream_t stream) {
+                             const float* d_key_norm_max, const float* d_uk, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws,
+                             size_t ws_bytes, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(u && q && d_n_tok && gsum && d_key_norm_max && cand && d_count && ws && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)q % 16) == 0);
@@ -2107,9 +2140,13 @@ int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const 
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, topk, max_candidates, &w, false)) return SIXDGS_E_WORKSPACE;
   const int k_eff = (int)(r < topk ? r : topk);
-  int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
-  if (st) return st;
-  hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info);
+  if (d_uk) {        // ray-sharded: U_(k) over the rays of ALL shards (the caller merged the shards' sixdgs_select_topk_u lists)
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, d_uk, q, d_key_norm_max, 1, 1, w.info);
+  } else {
+    int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info);
+  }
   const dim3 cg((unsigned)w.p.nbc, (unsigned)batch);
   hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
   hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
@@ -2121,7 +2158,8 @@ int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const 
 
 int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
                           const float* ctok, const float* gsum, const int64_t* cand, const int32_t* d_count, int64_t r, int topk,
-                          int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+                          int max_candidates, int allow_fewer, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
+                          sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r >= 1 && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && planes && d_scale && ctok && gsum && cand && d_count && idx && val && d_status && ws &&
@@ -2136,7 +2174,7 @@ int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, con
                      d_n_tok, 0, ctok, gsum, cand, d_count, cmax, compact, w.cscore);
   const int st = run_topk(w.cscore, cmax, cmax, batch, topk, w.lidx, w.lval, w.topk_ws, s);
   if (st) return st;
-  hipLaunchKernelGGL(k_sel_emit, dim3((unsigned)batch), dim3(1024), 0, s, w.lidx, w.lval, cand, d_count, cmax, topk, k_eff, idx, val, d_status);
+  hipLaunchKernelGGL(k_sel_emit, dim3((unsigned)batch), dim3(1024), 0, s, w.lidx, w.lval, cand, d_count, cmax, topk, k_eff, allow_fewer, idx, val, d_status);
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -2178,9 +2216,9 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
     st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, ws, stage,
                              stream, prof);
     if (st) return st;
-    st = sixdgs_select_candidates(u, (int64_t)stride, r, qg, ng, nb, gsum, d_key_norm_max, topk, max_candidates, cand, count, ws, stage, stream);
+    st = sixdgs_select_candidates(u, (int64_t)stride, r, qg, ng, nb, gsum, d_key_norm_max, nullptr, topk, max_candidates, cand, count, ws, stage, stream);
     if (st) return st;
-    st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates,
+    st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates, 0,
                                idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, stream);
     if (st) return st;
   }

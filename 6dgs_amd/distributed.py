@@ -131,6 +131,16 @@ def world() -> int:
     return dist.get_world_size() if is_dist() else 1
 
 
+def all_counts(n: int, device) -> list:
+    """One integer per rank -> the list of all of them, in rank order, on every rank."""
+    if not is_dist():
+        return [int(n)]
+    t = torch.tensor([int(n)], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
+    bufs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [int(b.item()) for b in bufs]
+
+
 def broadcast_int(value: int, src: int, device) -> int:
     """One integer from rank `src` to every rank."""
     if not is_dist():
@@ -265,3 +275,78 @@ def score_topk_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[t
     idx, val, scores = ops.score_pass2(glob, n_tok, r_local, workspace, topk, used_planes=key_planes is not None, want_scores=want_scores)
     gidx, gval = merge_topk(idx, val, ray_offset, topk, group)
     return gidx, gval, scores
+
+
+def kth_largest_of_union(val_local: torch.Tensor, k: int, group=None) -> torch.Tensor:
+    """Per-rank descending top-k value lists [B,k] (NaN-padded) -> the k-th largest value of their union, per image [B] (the
+    union of the shards' top-k lists contains the scene's top-k as a multiset).  -inf where the union holds fewer than k values."""
+    v = val_local
+    if is_dist() and group is not False:
+        world = dist.get_world_size(group)
+        c = _collective_device(v.contiguous())
+        bufs = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(bufs, c, group=group)
+        v = torch.cat(bufs, dim=1).to(val_local.device)
+    v = torch.where(torch.isnan(v), torch.full_like(v, -float("inf")), v)
+    return torch.sort(v, dim=1, descending=True).values[:, k - 1].contiguous()
+
+
+def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    if not is_dist():
+        return t
+    c = _collective_device(t.contiguous())
+    dist.all_reduce(c, op=op, group=group)
+    if c is not t:
+        t.copy_(c.to(t.device))
+    return t
+
+
+def score_select_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
+                             sample_scale: torch.Tensor, ray_offset: int, r_total: int, r_sample_total: int, topk: int = 100,
+                             max_candidates: Optional[int] = None, n_tok_host=None, profile=None, group=None, stream_state=None):
+    """The select path (top-k without materialised logits, include/sixdgs.h: sixdgs_score_select) over a scene whose key planes are
+    split across the ranks of `group`; this rank holds the planes of rays [ray_offset, ray_offset + r_local) and of ITS share of the
+    ray sample.  Per image and batch the ranks exchange: the sample's row statistics (2 all-reduces of 1 KB), the exact per-token
+    sums g_t after the sweep (1 all-reduce of 1 KB), the largest key norm (4 B), their k largest U (all-gather of k floats), the
+    statuses (4 B) and the per-rank exact top-k candidates (all-gather of k (index, value) pairs) -- a few KB, latency-bound; the
+    matrix-core sweep itself runs on local planes only.
+
+    Returns (global idx [B,k], val [B,k], status [B] host list): the first two identical on every rank and equal to the single-GPU
+    select answer up to the rounding of the per-token sums (the same 100 rays, values <= 2e-6); status[b] = candidates examined over
+    all ranks, or -1 when some rank could not decide image b (too many candidates / exponent overflow) -- the caller then scores
+    those images with score_topk_ray_sharded (all ranks take that decision together: the status is all-reduced)."""
+    from . import ops
+
+    r_local = key_planes.shape[0]
+    cmax = ops.SELECT_MAX_CANDIDATES if max_candidates is None else int(max_candidates)
+    ss = ops.SelectStream(q, n_tok, r_local, topk, cmax, n_tok_host)
+    stats = merge_row_stats(ss.sample_stats(sample_planes, sample_scale), group)             # identical ctok on every rank
+    ss.prepare(stats, r_sample_total, r_total)
+    ss.sweep(key_planes, key_scale, 0, profile)
+    _all_reduce(ss.gsum, dist.ReduceOp.SUM, group)                                            # exact g_t over ALL rays
+    _all_reduce(ss.key_norm, dist.ReduceOp.MAX, group)
+    uk = kth_largest_of_union(ss.topk_u(), min(topk, r_total), group)                         # U_(k) of the scene
+    cand, count = ss.candidates(uk=uk)
+    idx, val, status = ss.rescore(key_planes, key_scale, cand, count, compact=False, allow_fewer=True)
+    st = status.to(torch.int64)
+    bad = _all_reduce((st < 0).to(torch.int64), dist.ReduceOp.MAX, group) if is_dist() else (st < 0).to(torch.int64)
+    tot = _all_reduce(st.clamp(min=0), dist.ReduceOp.SUM, group) if is_dist() else st.clamp(min=0)
+    gidx, gval = merge_topk(idx, val, ray_offset, topk, group)
+    out_status = torch.where(bad > 0, torch.full_like(tot, -1), tot).tolist()
+    for b, v in enumerate(out_status):
+        if v < 0:
+            gidx[b], gval[b] = -1, float("nan")
+    return gidx, gval, out_status
+
+
+def gather_selected_rays(gidx: torch.Tensor, ori_local: torch.Tensor, dir_local: torch.Tensor, ray_offset: int, group=None):
+    """Global ray indices [B,k] (-1 = none) of a ray-sharded scene -> (ori [B,k,3], dir [B,k,3]) on every rank: each rank fills in
+    the rays it owns, one all-reduce (SUM) of 6 floats per selected ray puts them together (every index has exactly one owner)."""
+    r_local = ori_local.shape[0]
+    loc = gidx - int(ray_offset)
+    mine = (gidx >= 0) & (loc >= 0) & (loc < r_local)
+    safe = torch.where(mine, loc, torch.zeros_like(loc))
+    both = torch.cat([ori_local[safe], dir_local[safe]], dim=-1) * mine[..., None].to(ori_local.dtype)
+    if is_dist() and group is not False:
+        _all_reduce(both, dist.ReduceOp.SUM, group)
+    return both[..., :3].contiguous(), both[..., 3:].contiguous()

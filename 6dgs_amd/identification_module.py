@@ -113,13 +113,14 @@ class IdentificationModule(torch.nn.Module):
 
     KEEP_FP32_KEYS_BELOW = 4_000_000   # rays; above, only the bf16 planes are cached (2304 B/ray vs 1536 + 2304)
 
-    def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None):
+    def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None, sample_min_rays: Optional[int] = None):
         w = self.packed_weights(rays_ori.device)
         # Identity of the cache entry: the three ray tensor OBJECTS (held strongly, so the allocator cannot hand their
         # addresses to a new ray set while the entry lives), their in-place versions, the weights and the MMA mode.
         mode = ops.effective_mma_mode()
         fmt = "f32" if mode == ops.MMA_F32 else ("f16-planes" if mode in ops.F16_MODES else "bf16-planes")   # F16X3 / F16X3_L32 share planes
-        ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, fmt)
+        smin = ops.SELECT_MIN_RAYS if sample_min_rays is None else int(sample_min_rays)     # scenes from this size get the select path's ray sample
+        ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, fmt, rays_ori.shape[0] >= smin)
         held = self._key_cache_rays
         same = (self._key_cache is not None and self._key_cache_id == ident and held is not None
                 and all(h is t or (h.data_ptr() == t.data_ptr() and h.shape == t.shape and h.stride() == t.stride())   # a view of
@@ -138,7 +139,7 @@ class IdentificationModule(torch.nn.Module):
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
                 planes = None
             sample = None
-            if planes_mode and mode in ops.F16_MODES and r >= ops.SELECT_MIN_RAYS:
+            if planes_mode and mode in ops.F16_MODES and r >= smin:
                 # the ray sample of the select path (ops.score_select): one ray in 16 through the same ray MLP (+6 % set-up work,
                 # +96 B per ray); its planes carry their own tile scales
                 si = ops.select_sample_indices(r, rays_ori.device)
@@ -268,6 +269,47 @@ class IdentificationModule(torch.nn.Module):
                                              images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
                                              key_planes=kc["planes"], key_scale=kc["scale"])
         return idx, val, scores
+
+    @torch.no_grad()
+    def score_tokens_ray_sharded(self, token_list, rays_ori, rays_dir, rays_rgb, ray_offset: int, r_total: int, rays_to_output: int = 100,
+                                 group=None, profile=None, use_select: bool = True):
+        """The scorer over a scene whose RAYS are split across the ranks (SURVEY 8(e) fallback: key planes that fit only across
+        several GPUs -- cfg-4's 786 GB at N >= 4 -- or one image scored by several GPUs).  This rank holds rays
+        [ray_offset, ray_offset + len(rays_ori)) of r_total and keeps THEIR key planes resident (no per-step ray MLP, which is half
+        of a streamed step); every rank passes the SAME tokens.  Select path (distributed.score_select_ray_sharded) when only the
+        top-k is wanted and every rank has a ray sample; images it cannot decide, and use_select=False, take the two-pass cut
+        (distributed.score_topk_ray_sharded).  Returns (global idx [B,k], val [B,k]) identical on every rank."""
+        from . import distributed as dd
+        dev, k = rays_ori.device, rays_to_output
+        world = dd.world()
+        kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb, sample_min_rays=max(4096, ops.SELECT_MIN_RAYS // max(world, 1)))
+        q, n_tok, n_host = self._tokens_to_q(token_list, dev)
+        f16 = ops.effective_mma_mode() in ops.F16_MODES
+        have = torch.tensor([1 if (kc.get("sample") is not None and f16 and use_select and ops.select_enabled() and k <= ops.SELECT_MAX_CANDIDATES) else 0,
+                             0 if kc.get("sample") is None else int(kc["sample"][0].shape[0])], dtype=torch.int64, device=dev)
+        if dd.is_dist():
+            flag, cnt = have[:1].clone(), have[1:].clone()
+            dd._all_reduce(flag, torch.distributed.ReduceOp.MIN, group)
+            dd._all_reduce(cnt, torch.distributed.ReduceOp.SUM, group)
+            have = torch.cat([flag, cnt])
+        use, r_sample_total = bool(int(have[0])), int(have[1])
+        b = q.shape[0]
+        idx = torch.full((b, k), -1, dtype=torch.int64, device=dev)
+        val = torch.full((b, k), float("nan"), device=dev)
+        redo = list(range(b))
+        self.last_scoring_path = f"ray-sharded x{world} two-pass"
+        if use:
+            idx, val, st = dd.score_select_ray_sharded(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], ray_offset, r_total,
+                                                       r_sample_total, k, n_tok_host=n_host, profile=profile, group=group)
+            self.last_select_candidates = st
+            redo = [i for i, v in enumerate(st) if v < 0]
+            self.last_scoring_path = f"ray-sharded x{world} select" + (f"+two-pass({len(redo)})" if redo else "")
+        if redo:
+            sel = torch.tensor(redo, device=dev)
+            i2, v2, _ = dd.score_topk_ray_sharded(q[sel].contiguous(), n_tok[sel].contiguous(), kc["key"], ray_offset, k, key_planes=kc["planes"],
+                                                  key_scale=kc["scale"], group=group)
+            idx[sel], val[sel] = i2, v2
+        return idx, val
 
     @torch.no_grad()
     def score_tokens_streamed(self, token_list, rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100, chunk_rays: int = 8_388_608,

@@ -586,6 +586,36 @@ class SelectStream:
                                       _p(self.ctok), _p(self.gsum), _p(self.ws), self.ws.numel(), _stream()), "select_begin")
 
     @_on_device
+    def sample_stats(self, sample_planes, sample_scale) -> torch.Tensor:
+        """First half of begin(): (max, sumexp) [B,256,2] of the given sample -- ray-sharded scenes merge them across the shards."""
+        _need_gpu(self.q, sample_planes, sample_scale)
+        lib = _lib.load()
+        self._grow(lib.sixdgs_select_workspace_bytes(sample_planes.shape[0], self.b, self.topk, self.cmax))
+        stats = torch.empty(self.b, MAX_TOKENS, 2, device=self.dev)
+        check(lib.sixdgs_select_sample_stats(_p(self.q), _p(self.n_tok), self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0],
+                                             _p(stats), _p(self.ws), self.ws.numel(), _stream()), "select_sample_stats")
+        return stats
+
+    @_on_device
+    def prepare(self, stats: torch.Tensor, r_sample_total: int, r_total: int):
+        """Second half of begin(): the (merged) sample statistics and the TOTAL sample / ray counts of the scene -> ctok; gsum = 0."""
+        stats = _f32(stats)
+        _need_gpu(self.q, stats)
+        check(_lib.load().sixdgs_select_prepare(_p(stats), _p(self.n_tok), self.b, int(r_sample_total), int(r_total), _p(self.ctok), _p(self.gsum),
+                                                _stream()), "select_prepare")
+
+    @_on_device
+    def topk_u(self) -> torch.Tensor:
+        """The k largest U of the rays swept so far, per image, descending (NaN-padded when there are fewer than k rays)."""
+        lib = _lib.load()
+        _need_gpu(self.q)
+        self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
+        val = torch.empty(self.b, self.topk, device=self.dev)
+        check(lib.sixdgs_select_topk_u(_p(self.u), self.stride, self.r, self.b, self.topk, _p(val), _p(self.ws), self.ws.numel(), _stream()),
+              "select_topk_u")
+        return val
+
+    @_on_device
     def sweep(self, planes, scale, ray_offset: int, profile: Optional["KernelProfile"] = None):
         if ray_offset % 256:
             raise RuntimeError("6dgs_amd: select sweep chunks must start at a multiple of 256 rays")
@@ -599,20 +629,23 @@ class SelectStream:
         key_norm_max(planes, scale, out=self.key_norm)
 
     @_on_device
-    def candidates(self):
-        """-> (cand [B,cmax] int64 ascending ray indices, count [B] int32 on the device)"""
+    def candidates(self, uk: Optional[torch.Tensor] = None):
+        """-> (cand [B,cmax] int64 ascending ray indices, count [B] int32 on the device).  uk [B]: the k-th largest U of the WHOLE
+        scene (ray-sharded callers, from the merged topk_u lists); default: of this object's rays."""
         lib = _lib.load()
         _need_gpu(self.q)
         self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
         cand = torch.zeros(self.b, self.cmax, dtype=torch.int64, device=self.dev)
         count = torch.empty(self.b, dtype=torch.int32, device=self.dev)
+        uk = _f32(uk) if uk is not None else None
         check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.q), _p(self.n_tok), self.b, _p(self.gsum), _p(self.key_norm),
-                                           self.topk, self.cmax, _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
+                                           _p(uk), self.topk, self.cmax, _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
         return cand, count
 
     @_on_device
-    def rescore(self, planes, scale, cand, count, compact: bool):
-        """-> (idx [B,k], val [B,k], status [B] int32)"""
+    def rescore(self, planes, scale, cand, count, compact: bool, allow_fewer: bool = False):
+        """-> (idx [B,k], val [B,k], status [B] int32).  allow_fewer: fewer than k candidates is an answer (-1 / NaN padded), not a
+        refusal -- a shard of a ray-sharded scene."""
         lib = _lib.load()
         _need_gpu(self.q, planes, scale, cand, count)
         idx = torch.empty(self.b, self.topk, dtype=torch.int64, device=self.dev)
@@ -620,7 +653,7 @@ class SelectStream:
         status = torch.empty(self.b, dtype=torch.int32, device=self.dev)
         self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
         check(lib.sixdgs_select_rescore(_p(self.q), _p(self.n_tok), self.b, _p(planes), _p(scale), 1 if compact else 0, _p(self.ctok),
-                                        _p(self.gsum), _p(cand), _p(count), self.r, self.topk, self.cmax, _p(idx), _p(val), _p(status),
+                                        _p(self.gsum), _p(cand), _p(count), self.r, self.topk, self.cmax, 1 if allow_fewer else 0, _p(idx), _p(val), _p(status),
                                         _p(self.ws), self.ws.numel(), _stream()), "select_rescore")
         return idx, val, status
 

@@ -12,6 +12,10 @@ host sync is the ragged ray count, where the reference syncs too.  Extensions be
   emitter          "quadricell" (live path) | "isocell" (pose_estimation/isocell.py: K directions per
                    ellipsoid, what BASELINE.json's "64 / 256 isocell rays per ellipsoid" describes)
   perm             the subsample permutation (otherwise torch.randperm, as the reference)
+  shard            (rank, world): emit only this rank's contiguous block of the selected ellipsoids (ray-sharded scenes,
+                   SURVEY 8(e) fallback).  The normals still come from the 20-NN search over ALL selected ellipsoids, so the
+                   concatenation of the shards' rays in rank order IS the unsharded ray set.  Blocks are whole multiples of 256
+                   ellipsoids (every shard's first ray then sits on a key-tile boundary of the unsharded scene).
 """
 from __future__ import annotations
 
@@ -20,6 +24,13 @@ from typing import Optional
 import torch
 
 from . import ops
+
+
+def shard_block(n: int, rank: int, world: int, granule: int = 256):
+    """[lo, hi) of rank's block of n ellipsoids: equal blocks rounded up to whole granules, the last rank(s) take what is left."""
+    per = -(-n // world)
+    per = -(-per // granule) * granule
+    return min(rank * per, n), min((rank + 1) * per, n)
 
 
 @torch.no_grad()
@@ -34,6 +45,7 @@ def generate_all_possible_rays(
     perm: Optional[torch.Tensor] = None,
     k_neighbors: int = 20,
     return_src: bool = False,
+    shard: Optional[tuple] = None,
 ):
     xyz, log_scale, rot = model._xyz, model._scaling, model._rotation
     if not xyz.is_cuda:
@@ -54,6 +66,9 @@ def generate_all_possible_rays(
     sel = sel.contiguous()
     centres = xyz[sel].contiguous()
     normals = ops.normals_knn(centres, centres, k_neighbors) if sel.shape[0] else torch.empty(0, 3, device=dev)
+    if shard is not None:
+        lo, hi = shard_block(int(sel.shape[0]), int(shard[0]), int(shard[1]))
+        sel, normals = sel[lo:hi].contiguous(), normals[lo:hi].contiguous()
     if emitter == "quadricell":
         ori, dr, rgb, src, _ = ops.emit_quadricell(xyz, log_scale, rot, model._features_dc, model._features_rest,
                                                    int(model.active_sh_degree), sel, normals, int(sample_quadricell_targets))

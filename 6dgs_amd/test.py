@@ -156,6 +156,35 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
     return sol
 
 
+@torch.no_grad()
+def estimate_poses_ray_sharded(id_module, images, rays_ori, rays_dirs, rays_rgb, ray_offset: int, r_total: int, gt_c2w=None, k: int = 100,
+                               profile=None, tokens=None, up=None, image_graph: bool = True, group=None):
+    """estimate_poses for a scene whose rays are split across the ranks (this rank: rays [ray_offset, ray_offset + len(rays_ori)) of
+    r_total, key planes resident): EVERY rank passes the same images, runs the (cheap) image side itself, scores its ray slice
+    (IdentificationModule.score_tokens_ray_sharded), and the 100 selected rays of each image are put together from their owners
+    (distributed.gather_selected_rays) for the pose solve, which every rank then runs identically."""
+    from . import distributed as dd
+    if tokens is None:
+        res = None
+        if image_graph and not torch.cuda.is_current_stream_capturing():
+            cache = id_module.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
+            res = cache.run(id_module, images)
+        if res is not None and not isinstance(res[0], (list, tuple)):
+            tokens, up = res
+        else:
+            imgs_f, masks = prepare_images_device(images)
+            tokens, fmaps = id_module.image_tokens(imgs_f, masks)
+            up = id_module.camera_up(fmaps)
+    idx, weights = id_module.score_tokens_ray_sharded(tokens, rays_ori, rays_dirs, rays_rgb, ray_offset, r_total, k, group=group, profile=profile)
+    sel_o, sel_d = dd.gather_selected_rays(idx, rays_ori, rays_dirs, ray_offset, group)
+    b = idx.shape[0]
+    compact = torch.arange(b * k, device=idx.device, dtype=torch.int64).view(b, k)
+    compact = torch.where(idx >= 0, compact, idx)
+    sol = ops.solve_pose(sel_o.reshape(-1, 3), sel_d.reshape(-1, 3), compact, weights, up, gt_c2w)
+    sol.update(idx=idx, weights=weights, scores=None, tokens=tokens, up=up)
+    return sol
+
+
 def gt_pose_and_intrinsics(camera_info, device):
     """test.py:47-67 (on the host: 4x4 inverse of [R^T | T])."""
     w2c = torch.eye(4, dtype=torch.float32)

@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--scoring", choices=["resident", "streamed"], default=None,
                     help="resident: key planes cached in HBM (1536 B/ray); streamed: ray chunks whose keys are computed, used and dropped")
     ap.add_argument("--chunk-rays", type=int, default=8_388_608, help="streamed scorer: rays per chunk")
+    ap.add_argument("--parallelism", choices=["image", "ray"], default="image",
+                    help="image: query images shard over the ranks, every rank holds the whole scene (north_star; default).  ray: the RAYS shard "
+                         "over the ranks, every rank keeps the key planes of its slice resident and all ranks score the same --batch images per "
+                         "step -- for scenes whose key planes fit only across GPUs (cfg4 at N >= 4: 786 GB / N per GPU, no per-step ray MLP)")
     ap.add_argument("--mode", choices=["full", "reference"], default="full",
                     help="full: every Gaussian, iso-cell emitter (headline); reference: 1000-ellipsoid quadricell subsample")
     ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f16x3l32", "f32"], default="default",
@@ -159,9 +163,14 @@ def main():
     dd.broadcast_module(idm, 0)
     torch.cuda.synchronize()
     t0 = time.time()
+    ray_sharded = args.parallelism == "ray"
+    if ray_sharded and args.mode != "full":
+        raise SystemExit("--parallelism ray needs --mode full")
+    if ray_sharded:
+        args.scoring = "resident"              # the point of ray sharding: every rank's slice of the key planes stays in HBM
     if args.mode == "full":
         ori, dr, rgb = pkg.generate_all_possible_rays(scene, max_ellipsoids=-1, emitter="isocell",
-                                                      rays_per_ellipsoid=args.rays_per_ellipsoid)
+                                                      rays_per_ellipsoid=args.rays_per_ellipsoid, shard=(rank, world) if ray_sharded else None)
         finite = torch.isfinite(dr).all(dim=1)   # normals exactly (anti)parallel to z give NaN rays (isocell.py:208-212)
         if not bool(finite.all()):
             ori, dr, rgb = ori[finite].contiguous(), dr[finite].contiguous(), rgb[finite].contiguous()
@@ -171,12 +180,16 @@ def main():
     torch.cuda.synchronize()
     t_emit = time.time() - t0
     R = int(ori.shape[0])
+    ray_offset, R_total = 0, R
+    if ray_sharded and world > 1:               # this rank's rays are [ray_offset, ray_offset + R) of R_total
+        counts = dd.all_counts(R, dev)
+        ray_offset, R_total = sum(counts[:rank]), sum(counts)
     streamed = args.scoring == "streamed"
     kprof = ops.KernelProfile()
     t0 = time.time()
     ws, inflight, k_ms, k_fl = None, args.batch, 0.0, 0.0
     if not streamed:
-        idm._ensure_keys(ori, dr, rgb, profile=kprof)
+        idm._ensure_keys(ori, dr, rgb, profile=kprof, sample_min_rays=max(4096, ops.SELECT_MIN_RAYS // world) if ray_sharded else None)
         torch.cuda.synchronize()
         k_ms, k_fl, _, _ = kprof.collect()
     t_keys = time.time() - t0
@@ -192,6 +205,8 @@ def main():
     # the select path (top-k without materialised logits) serves the timed steps when the scene has a ray sample; the two-pass
     # workspace (784 B per ray and image) is then only needed for its fallback and for the secondary two-pass figures
     use_select = (not streamed and not args.graph and ops.select_enabled() and idm._key_cache is not None and idm._key_cache.get("sample") is not None)
+    if ray_sharded:
+        use_select = False                      # (the ray-sharded scorer decides select / two-pass itself, all ranks together)
 
     def two_pass_ws():
         nonlocal ws
@@ -201,12 +216,13 @@ def main():
             ws = torch.empty(ops.score_topk_workspace_bytes(R, inflight, 100), dtype=torch.uint8, device=dev)
         return ws
 
-    if not streamed and not use_select:
+    if not streamed and not use_select and not ray_sharded:
         two_pass_ws()
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------
-    cams = syn.make_cameras(args.batch, 100 + rank, width=args.image_size, height=args.image_size)
+    # image-sharded: every rank its own images; ray-sharded: every rank the SAME images (each scores them against its ray slice)
+    cams = syn.make_cameras(args.batch, 100 + (0 if ray_sharded else rank), width=args.image_size, height=args.image_size)
     images = [torch.from_numpy(c["image"]).to(dev) for c in cams]
     gts = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams]).to(dev)
     tp.prime_image_graph(idm, images)        # set-up, like the key cache: the hipGraph of the image side for this batch shape
@@ -216,6 +232,8 @@ def main():
     graph, graph_sol = None, None
 
     def run_batch(p):
+        if ray_sharded:
+            return tp.estimate_poses_ray_sharded(idm, images, ori, dr, rgb, ray_offset, R_total, gt_c2w=gts, profile=p)
         return tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p,
                                  streamed_chunk_rays=args.chunk_rays if streamed else None)
 
@@ -225,6 +243,8 @@ def main():
             sol = graph_sol
         else:
             sol = run_batch(p)
+        if ray_sharded:                                          # every rank solved the same poses: nothing to gather
+            return sol["c2w"].cpu(), sol
         c2w, st = dd.gather_poses(sol["c2w"], sol["status"], 0)
         host = (c2w if c2w is not None else sol["c2w"]).cpu()   # all poses on the host = end of the step
         return host, sol
@@ -269,7 +289,7 @@ def main():
     # ---- the same workload through the two-pass scorer: 24-bit fixed-point logits between the passes, and fp32 logits (VERDICT r1:
     # keep the cost of not narrowing visible).  The select path above stores no logits at all and re-scores its candidates in fp32.
     l32, l24 = None, None
-    n32 = (min(args.steps, 3) if args.l32_steps < 0 else args.l32_steps) if (mode == ops.MMA_F16X3 and not args.graph and not streamed) else 0
+    n32 = (min(args.steps, 3) if args.l32_steps < 0 else args.l32_steps) if (mode == ops.MMA_F16X3 and not args.graph and not streamed and not ray_sharded) else 0
     if n32 > 0:
         two_pass_ws()
         ops.set_select_enabled(False)
@@ -288,36 +308,42 @@ def main():
                "ms_per_step": round(1e3 * e32 / n32, 3),
                "note": "two-pass scorer, logits between the passes as fp32 (1024 B/ray/image): no intermediate below fp32"}
 
-    poses = world * args.batch * args.steps
+    img_ranks = 1 if ray_sharded else world          # ray-sharded: all ranks work on the same args.batch images of a step
+    poses = img_ranks * args.batch * args.steps
     value = poses / elapsed
     med = statistics.median(per_step)
     out = {
         "metric": "poses/sec", "value": round(value, 4), "unit": "poses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "median_step": {"ms": round(1e3 * med, 3), "poses_per_s": round(world * args.batch / med, 4), "n": len(per_step),
+        "scaling": "strong" if ray_sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "median_step": {"ms": round(1e3 * med, 3), "poses_per_s": round(img_ranks * args.batch / med, 4), "n": len(per_step),
                         "min_ms": round(1e3 * min(per_step), 3), "max_ms": round(1e3 * max(per_step), 3),
                         "note": "rank-0 wall time of each timed step (every step ends with the poses on the host)"},
         "arithmetic": ("fp32 results; q.K^T and the ray MLP / k_proj as 2 power-of-two-scaled fp16 planes x 3 MFMA terms (q_proj, CNN: 3 bf16 planes x 6 "
                        "terms), fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
-                       + ("; select path: no logits stored, candidates re-scored in fp32 (nothing below fp32 on the path)" if path.startswith("select") else
+                       + ("; select path: no logits stored, candidates re-scored in fp32 (nothing below fp32 on the path)" if ("select" in path and not path.startswith("streamed")) else
                           ("; logits travel between the two scorer passes as 24-bit fixed point, absolute error <= 2^-20 per logit "
                            "(fp32_logits_mode = the same run without that narrowing)" if mode == ops.MMA_F16X3 else ""))),
         "config": {
             "workload": (f"{args.config}: synthetic {args.gaussians}-Gaussian scene" + (" (through a 3DGS PLY file)" if args.scene == "ply" else "") + ", "
                          + (f"iso-cell emission from every valid Gaussian x {args.rays_per_ellipsoid} rays" if args.mode == "full"
                             else "reference-mode quadricell emission from 1000 sampled ellipsoids")
-                         + f" (R={R} rays), {args.image_size}x{args.image_size} uint8 queries, 256 tokens x 384, top-100, "
-                         f"{args.batch} images/GPU/step; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
-            "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R, "images_per_gpu_per_step": args.batch,
+                         + f" (R={R_total} rays), {args.image_size}x{args.image_size} uint8 queries, 256 tokens x 384, top-100, "
+                         + (f"{args.batch} images/step scored by all {world} ranks (each on its ray slice)" if ray_sharded else f"{args.batch} images/GPU/step")
+                         + "; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
+            "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R_total, "images_per_gpu_per_step": args.batch,
             "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
-            "parallelism": f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)",
+            "parallelism": (f"ray-sharded x{world} (scene broadcast over RCCL, every rank emits and keeps the key planes of its block of ellipsoids: "
+                            f"{R} of {R_total} rays on rank 0; per batch a few KB of all-reduce / all-gather: sample statistics, g_t, U_(k), candidates)"
+                            if ray_sharded else f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)"),
             "mma": mma_name[mode],
         },
         "ranks_seen": ranks_seen, "backend": dd.backend_name(),
         "scene_setup_s": {"total": round(t_setup, 3), "normals+emission": round(t_emit, 3), "ray_mlp_keys": round(t_keys, 3),
                           "ray_mlp_keys_tflops": round(k_fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None},
     }
+    if os.environ.get("SIXDGS_BENCH_DUMP_POSES"):        # test hook: the poses of the last timed step in the line
+        out["poses_last_step"] = sol["c2w"].cpu().tolist()
     if streamed:
         out["config"]["chunk_rays"] = args.chunk_rays
         out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj and the scorer "
@@ -336,7 +362,7 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight and tj.get("path", "two-pass") == ("select" if path.startswith("select") else "two-pass"):
+                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight and tj.get("path", "two-pass") == ("select" if ("select" in path and not path.startswith("streamed")) else "two-pass"):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = ("%s -- builder's separate rocprofv3 --pmc pass over this same command (round %s), NOT measured in this run"
                                       % (tj.get("source", os.path.relpath(args.traffic_json, ROOT)), tj.get("round")))
@@ -351,7 +377,7 @@ def main():
                        ops.MMA_F16X3: ("k_logits_f16x<UB> (select path): K.Q^T (256 rays x 256 tokens per tile) with fp32 operands scaled by a power of two "
                                        "and split into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA "
                                        "rings; epilogue exp2 + token-sum butterfly, 16 B per ray and image leave the chip (no logits)"
-                                       if path.startswith("select") else
+                                       if ("select" in path and not path.startswith("streamed")) else
                                        "k_logits_f16x: q.K^T (256 tokens x 256 rays per tile) with fp32 operands scaled by a power of two and split "
                                        "into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA rings, "
                                        "online row stats, logits stored once as 24-bit fixed point"),
@@ -369,10 +395,10 @@ def main():
         }
     # ---- secondary figure: the reference's own emission (1000 sampled ellipsoids, quadricell: R ~ 28.7 k), where the per-pose cost is
     # the image side (ViT + CNN) and launch overhead, not the scorer.  Every rank runs it (image-sharded like the headline).
-    if args.mode == "full" and not args.skip_reference_mode and not streamed and not args.graph:
+    if args.mode == "full" and not args.skip_reference_mode and not streamed and not args.graph and not ray_sharded:
         out["reference_mode"] = reference_mode_figure(args, pkg, syn, tp, dd, idm, scene, dev, rank, world)
     if rank == 0:
-        if world == 1 and not args.skip_cpu_baseline:
+        if world == 1 and not args.skip_cpu_baseline and not ray_sharded:
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline(args, idm, ori, dr, rgb, R, sol, gts)
             # BASELINE.json's metric is "poses/sec ...; mean rot/trans err": the second half, answered from this line alone
             pv = out["parity_vs_oracle"]

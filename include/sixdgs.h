@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -303,15 +303,29 @@ size_t sixdgs_select_workspace_bytes(int64_t r, int batch, int topk, int max_can
 size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);   /* candidates (r = all rays), rescore */
 int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
                         int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+/* Ray-sharded select (the scene's key planes split over ranks, SURVEY 8(e) fallback): `begin` in two halves, so that the shards can
+ * merge their sample statistics in between -- sample_stats writes this shard's (max, sumexp) [B,256,2] of ITS sample; the caller
+ * merges (M = max, S = sum s e^(m - M): two all-reduces of 1 KB per image) and hands the global statistics to prepare together with
+ * the TOTAL sample and ray counts.  Then per shard: sweep -> all-reduce(SUM) of gsum, all-reduce(MAX) of the key norm ->
+ * sixdgs_select_topk_u (the shard's k largest U, descending, NaN-padded) -> all-gather, k-th largest of the union = U_(k) of the
+ * scene -> candidates with d_uk [B] -> rescore with allow_fewer (a shard may hold fewer than k candidates: idx / val are then padded
+ * with -1 / NaN and status = candidates examined) -> all-gather + (value desc, global index asc) merge. */
+int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+                               int64_t r_sample, float* row_stats /*[B,256,2]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+int sixdgs_select_prepare(const float* row_stats, const int32_t* d_n_tok, int batch, int64_t r_sample, int64_t r_total, float* ctok, float* gsum,
+                          sixdgs_stream_t stream);
+int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, int batch, int topk, float* val /*[B,topk]*/, void* ws, size_t ws_bytes,
+                         sixdgs_stream_t stream);        /* ws: sixdgs_select_candidates_workspace_bytes */
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
                         const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
                         size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
 int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
-                             const float* d_key_norm_max, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes,
-                             sixdgs_stream_t stream);
+                             const float* d_key_norm_max, const float* d_uk /*[B] k-th largest U of the whole scene, or NULL = of these rays*/,
+                             int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
                           const float* ctok, const float* gsum, const int64_t* cand, const int32_t* d_count, int64_t r, int topk,
-                          int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
+                          int max_candidates, int allow_fewer, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
+                          sixdgs_stream_t stream);
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy for the FLOP count, may be NULL*/,
                         int batch, const void* key_planes, const float* d_key_scale, const float* d_key_norm_max, int64_t r,
                         const void* sample_planes, const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,

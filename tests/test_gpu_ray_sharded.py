@@ -30,6 +30,54 @@ def test_two_ranks_ray_sharded_scorer_matches_single_gpu(mode, port):
     assert [r["rays"] for r in d["ranks"]] == [[0, 10112], [10112, 20037]]
 
 
+@pytest.mark.timeout(400)
+def test_two_ranks_ray_sharded_select_matches_single_gpu_select():
+    """the select path over a ray-sharded scene (per-rank sweep, all-reduce of the sample statistics / g_t / key norm,
+    all-gather of the per-rank top-k U -> global threshold, local candidates + local exact re-score, all-gather + merge): two ranks on
+    one GPU over gloo return the single-GPU select answer -- the same 100 rays, values <= 2e-6 -- and, with a candidate budget that
+    refuses every image, the ray-sharded two-pass scorer's (forced fall-back, all ranks deciding together)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    p = subprocess.run([sys.executable, "-W", "ignore", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29553", "tools/ray_shard_check.py", "--backend", "gloo",
+                        "--device", "0", "--select", "--rays", "300037"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=380)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["ok"], d
+    assert [r["rays"] for r in d["ranks"]] == [[0, 150272], [150272, 300037]]
+    assert d["ranks"][0]["select"] == d["ranks"][1]["select"]                 # identical answers on every rank
+
+
+@pytest.mark.timeout(500)
+def test_bench_ray_parallelism_two_ranks_and_module_path():
+    """`bench.py --parallelism ray`: every rank emits and keeps the key planes of its block of ellipsoids, all ranks score the same
+    images, the selected rays are gathered from their owners for the pose solve -- two ranks on one GPU over gloo give the poses of
+    the one-rank run of the same flag (which is the image-sharded run's scorer on the whole scene)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SIXDGS_BENCH_BACKEND="gloo", SIXDGS_BENCH_FORCE_DEVICE="0", SIXDGS_BENCH_DUMP_POSES="1")
+    outs = []
+    for n in (1, 2):
+        p = subprocess.run([sys.executable, "-W", "ignore", "bench.py", "--gpus", str(n), "--parallelism", "ray", "--gaussians", "40000", "--batch", "3",
+                            "--steps", "2", "--warmup", "1", "--skip-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=450)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-1000:]
+        outs.append(json.loads(lines[0]))
+    a, b = outs
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["scaling"] == "strong" and b["config"]["parallelism"].startswith("ray-sharded x2")
+    assert a["config"]["rays"] == b["config"]["rays"] == 40000 * 64
+    assert "select" in a["config"]["scoring_path"] and "select" in b["config"]["scoring_path"]
+    import numpy as np
+    pa, pb = np.asarray(a["poses_last_step"]), np.asarray(b["poses_last_step"])
+    assert pa.shape == pb.shape == (3, 4, 4) and np.abs(pa - pb).max() < 1e-4
+    assert abs(b["value"] - 3 * 2 / (b["ms_per_step"] * 2e-3)) < 1e-2 * b["value"]          # poses of ONE image set per step, not x world
+
+
 def test_single_process_split_passes_equal_the_fused_scorer():
     """pass 1 + pass 2 with the statistics handed straight back are the fused scorer, bit for bit."""
     if not torch.cuda.is_available():

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="force this device on every rank (single-GPU test boxes)")
     ap.add_argument("--rays", type=int, default=20_000)
     ap.add_argument("--mode", default="f16x3")
+    ap.add_argument("--select", action="store_true", help="check the ray-sharded SELECT path (distributed.score_select_ray_sharded) against the "
+                                                           "single-GPU select answer, then once more with a candidate budget so small that every "
+                                                           "image must fall back to the ray-sharded two-pass scorer")
     a = ap.parse_args()
     dd = importlib.import_module("6dgs_amd.distributed")
     ops = importlib.import_module("6dgs_amd.ops")
@@ -43,6 +46,8 @@ def main():
             return ops.split_planes_f16(k)
         return (ops.split_planes(k), None) if a.mode == "bf16x6" else (None, None)
 
+    if a.select:
+        return check_select(a, dd, ops, rank, world, dev, key, q, n, n_tok)
     # single-GPU result over all rays
     pl, sc = planes_of(key)
     idx0, val0, s0, _ = ops.score_topk(q, n_tok, key, 100, key_planes=pl, key_scale=sc)
@@ -64,6 +69,51 @@ def main():
     if rank == 0:
         print(json.dumps({"ranks": gathered, "ok": all(g["topk_idx_equal"] and g["scores_rel_err"] < 2e-6 and g["topk_val_rel_err"] < 2e-6
                                                           for g in gathered)}), flush=True)
+    dd.barrier()
+
+
+def check_select(a, dd, ops, rank, world, dev, key, q, n, n_tok):
+    """Every rank: the single-GPU select answer over ALL rays, then its slice through the module-level ray-sharded scorer."""
+    R = key.shape[0]
+    pl, sc = ops.split_planes_f16(key)
+    si = ops.select_sample_indices(R, dev)
+    spl, ssc = ops.split_planes_f16(key[si].contiguous())
+    idx0, val0, st0 = ops.score_select(q, n_tok, pl, sc, spl, ssc, 100)
+    i2, v2, _, _ = ops.score_topk(q, n_tok, None, 100, key_planes=pl, key_scale=sc, want_scores=False)
+    per = -(-R // world)
+    per = -(-per // 256) * 256
+    lo, hi = min(rank * per, R), min((rank + 1) * per, R)
+    kl = key[lo:hi].contiguous()
+    pl_l, sc_l = ops.split_planes_f16(kl)
+    si_l = ops.select_sample_indices(hi - lo, dev)
+    spl_l, ssc_l = ops.split_planes_f16(kl[si_l].contiguous())
+    rs_tot = sum(dd.all_counts(int(si_l.shape[0]), dev))
+    res = {}
+    # "forced_fallback": a nearly flat softmax (q x 5e-4: thousands of rays within the bounds) and room for 104 candidates per rank -- every
+    # image is refused on every rank together and goes through the ray-sharded two-pass scorer; reference = the single-GPU two-pass scorer
+    q_flat = q * 5e-4
+    if2, vf2, _, _ = ops.score_topk(q_flat, n_tok, None, 100, key_planes=pl, key_scale=sc, want_scores=False)
+    for name, cmax, qq, ref_i, ref_v in (("select", None, q, idx0, val0), ("forced_fallback", 104, q_flat, if2, vf2)):
+        gi, gv, st = dd.score_select_ray_sharded(qq, n_tok, pl_l, sc_l, spl_l, ssc_l, lo, R, rs_tot, 100, max_candidates=cmax, n_tok_host=n)
+        redo = [b for b, v in enumerate(st) if v < 0]
+        if redo:                                     # what IdentificationModule.score_tokens_ray_sharded does with refused images
+            sel = torch.tensor(redo, device=dev)
+            i3, v3, _ = dd.score_topk_ray_sharded(qq[sel].contiguous(), n_tok[sel].contiguous(), None, lo, 100, key_planes=pl_l, key_scale=sc_l)
+            gi[sel], gv[sel] = i3, v3
+        torch.cuda.synchronize()
+        same = [bool(set(gi[b].tolist()) == set(ref_i[b].tolist())) for b in range(q.shape[0])]
+        order = [bool(torch.equal(gi[b], ref_i[b])) for b in range(q.shape[0])]
+        vrel = float(((gv - ref_v).abs().max(dim=1).values / ref_v[:, 0]).max())
+        res[name] = {"status": st, "redo": redo, "same_set": same, "same_order": order, "val_rel_err": vrel}
+    out = {"rank": rank, "world": world, "rays": [lo, hi], "single_gpu_status": st0.tolist(), "single_gpu_select_equals_two_pass_set":
+           [bool(set(idx0[b].tolist()) == set(i2[b].tolist())) for b in range(q.shape[0])], **res}
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, out) if world > 1 else gathered.__setitem__(0, out)
+    if rank == 0:
+        ok = all(all(g[m]["same_set"]) and g[m]["val_rel_err"] < 2e-6 for g in gathered for m in ("select", "forced_fallback"))
+        ok = ok and all(min(g["select"]["status"]) >= 100 and g["select"]["redo"] == [] for g in gathered)
+        ok = ok and all(len(g["forced_fallback"]["redo"]) >= 2 for g in gathered)      # (the one-token image may still be decidable)
+        print(json.dumps({"ranks": gathered, "ok": bool(ok)}), flush=True)
     dd.barrier()
 
 
