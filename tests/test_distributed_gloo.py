@@ -143,6 +143,26 @@ def _worker_ray_shard(rank, world, port, q):
         ro = np.lexsort((np.broadcast_to(np.arange(R), ref.shape), -ref), axis=1)[:, :K]
         assert np.array_equal(gi.numpy(), ro), (gi[2, :12], ro[2, :12])
         assert np.array_equal(gv.numpy(), np.take_along_axis(ref, ro, axis=1))
+        # ray-sharded SELECT plumbing: U_(k) of the scene from the shards' top-k lists; the selected rays put together from their owners
+        u = rng.random((B, R)).astype(np.float32)
+        u[0, :] = np.round(u[0, :] * 20) / 20                                  # heavy ties in image 0
+        ul = np.sort(u[:, lo:hi], axis=1)[:, ::-1][:, :K].copy()
+        if rank == 1:
+            ul[2, 5:] = np.nan                                                 # a shard with only 5 rays for image 2
+        uk = dd.kth_largest_of_union(torch.from_numpy(ul), K).numpy()
+        full = u.copy()
+        full[2, lo1:hi1] = -np.inf
+        full[2, lo1:lo1 + 5] = np.sort(u[2, lo1:hi1])[::-1][:5]
+        assert np.array_equal(uk, np.sort(full, axis=1)[:, ::-1][:, K - 1])
+        assert dd.all_counts(hi - lo, "cpu") == [dd.shard_range(R, r_, world)[1] - dd.shard_range(R, r_, world)[0] for r_ in range(world)]
+        ori = torch.from_numpy(rng.standard_normal((R, 3)).astype(np.float32))
+        dr = torch.from_numpy(rng.standard_normal((R, 3)).astype(np.float32))
+        gsel = torch.from_numpy(rng.integers(0, R, size=(B, 17)))
+        gsel[1, 3] = -1
+        so, sd_ = dd.gather_selected_rays(gsel, ori[lo:hi], dr[lo:hi], lo)
+        want_o, want_d = ori[gsel.clamp(min=0)], dr[gsel.clamp(min=0)]
+        want_o[1, 3], want_d[1, 3] = 0.0, 0.0
+        assert torch.equal(so, want_o) and torch.equal(sd_, want_d)
         dd.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
