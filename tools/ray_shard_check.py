@@ -110,7 +110,9 @@ def check_select(a, dd, ops, rank, world, dev, key, q, n, n_tok):
     gathered = [None] * world
     torch.distributed.all_gather_object(gathered, out) if world > 1 else gathered.__setitem__(0, out)
     if rank == 0:
-        ok = all(all(g[m]["same_set"]) and g[m]["val_rel_err"] < 2e-6 for g in gathered for m in ("select", "forced_fallback"))
+        # "select": the same 100 rays; "forced_fallback": the softmax is flat to ~1e-4, the 100th and 101st scores tie within fp32 rounding,
+        # so the SETS may differ between two correct evaluations -- the sorted value lists must not
+        ok = all(all(g["select"]["same_set"]) and g[m]["val_rel_err"] < 2e-6 for g in gathered for m in ("select", "forced_fallback"))
         ok = ok and all(min(g["select"]["status"]) >= 100 and g["select"]["redo"] == [] for g in gathered)
         ok = ok and all(len(g["forced_fallback"]["redo"]) >= 2 for g in gathered)      # (the one-token image may still be decidable)
         print(json.dumps({"ranks": gathered, "ok": bool(ok)}), flush=True)
