@@ -12,6 +12,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "lib6dgs_hip.so")
+if os.environ.get("SIXDGS_LIB"):       # developer switch: a private build of the library (tools/build_variant.py); never set in production
+    LIB_PATH = os.path.abspath(os.environ["SIXDGS_LIB"])
 
 vp = C.c_void_p
 i64 = C.c_int64

@@ -18,11 +18,31 @@
 #include "gemm_kernel.h"
 #include "device_math.h"
 #include "dense.h"
+#include <cstdlib>
 
 using namespace sdg;
 
 namespace {
 
+#ifndef SDG_TILE_MAJOR
+#define SDG_TILE_MAJOR 0
+#endif
+// Layout of the chain's ACTIVATION planes in HBM.  Ray-major [ray][slab][128 B] (the default) makes every operand load a set of
+// 128-byte pieces 640 B .. 2 KB apart and every output store 512-byte pieces 2 KB apart.  Round 3 built the alternative, tile-major
+// [granule of 128 rays][slab][ray in granule][128 B] (-DSDG_TILE_MAJOR=1): a granule's share of a slab is 16 KB of consecutive bytes,
+// an epilogue unit writes 64 KB of consecutive bytes, a tile's working set is one 512 KB run -- and measured the SAME time to 0.3 %
+// (293 vs 294 TFLOP/s, with and without a per-granule pad against channel aliasing): the chain is not bound by the DRAM access
+// pattern.  (The first tile-major build ran at 172 TFLOP/s -- 112 spilled registers, not memory; see the epilogue's opaque copies.)
+constexpr bool kTileMajor = SDG_TILE_MAJOR != 0;
+constexpr int kGran = 128;            // rays per granule
+constexpr int kGranSlab = kGran * 128;   // bytes of one (granule, slab)
+#ifndef SDG_GRAN_PAD
+#define SDG_GRAN_PAD 4352
+#endif
+// Tile-major only: every granule is followed by kGranPad unused bytes, so that the granules of different tiles do not start at
+// addresses congruent modulo a power of two (channel aliasing between workgroups that walk their slabs in step).  Measured: no effect.
+constexpr int kGranPad = kTileMajor ? SDG_GRAN_PAD : 0;
+__host__ __device__ constexpr int64_t gran_stride(int ks) { return (int64_t)ks * kGranSlab + kGranPad; }
 constexpr int kSlabB = 128;           // bytes of one (row, slab): plane h 64 B, plane l 64 B
 constexpr int kPRow = 144;            // LDS row stride of a staged slab
 constexpr int kStRow = 528;           // staging row of the epilogue: 512 B of a ray + 16 B (with 512 the 32 lanes of a write hit one bank: 32-way conflict)
@@ -83,7 +103,7 @@ constexpr int kWStage = kWRows * kPRow;        // 73 728 B
 // Epilogue per pass: bias, ReLU, per-(ray, 128-feature block) power-of-two scale, fp16 split (all waves, in place), then per (block,
 // 128-ray half) LDS staging and coalesced 16-byte stores through the stage just consumed.
 template <int NTM, int NTN>
-__global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n_pass, unsigned total_tiles) {
+__global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n_pass, unsigned total_tiles, unsigned split) {
   constexpr int FP = 128 * NTM;          // features per pass
   constexpr int RT = 64 * NTN;           // rays per tile
   constexpr int kWL = 2 * NTM;           // weight loads per thread and slab (64 rows each); ray loads: 8 - kWL
@@ -100,7 +120,15 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   const int ks = A.ks0 + A.ks1;
   const int nb_all = A.n >> 7;
   f32x16 acc[NTM][NTN];
-  unsigned tile = blockIdx.x;
+  // split (two-pass layers, round 3): the two passes of a ray tile run in TWO sibling workgroups at the same time instead of one
+  // after the other in one workgroup -- work items w, w ^ 1 of the XCD remap sit on one XCD, start together and do identical work, so
+  // the sibling's reads of the tile's input planes hit that XCD's L2 (one workgroup's second pass came a full pass later, after 16 MB
+  // of other tiles had gone through the 4 MB L2: the input planes of the N = 512 layers were read from HBM twice).
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned pbase = split ? (w & 1u) : 0u;              // first pass of this workgroup ...
+  const unsigned npl = split ? 1u : n_pass;                  // ... and how many it runs per tile
+  const unsigned tstride = split ? gridDim.x >> 1 : gridDim.x;
+  unsigned tile = split ? w >> 1 : w;
   int64_t ray0 = (int64_t)tile * RT;
 
   int shn[kNS];      // the shifts this thread moves into the table (first tile: now; later tiles: fetched at the tile switch, stored one slab later)
@@ -126,7 +154,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 8 instructions x 64
   // rows per slab.  A load's address is a uniform base (scalar unit) + a 32-bit offset, three VALU operations per load; loads are
   // unconditional with clamped rows.
-  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16;
+  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16, t16 = (unsigned)tid * 16u;
   unsigned lt = tile, lb = 0;      // load cursor: tile, pass and slab of the next fetch
   int ls = 0;
   const char *abase0, *abase1;
@@ -134,8 +162,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #define SDG_TILEBASE()                                                                   \
   {                                                                                      \
     const int64_t r0_ = (int64_t)lt * RT;                                                \
-    abase0 = A.a0 + (r0_ * A.ks0) * kSlabB;                                              \
-    abase1 = A.a1 ? A.a1 + (r0_ * A.ks1) * kSlabB : abase0;                              \
+    abase0 = kTileMajor ? A.a0 + (r0_ >> 7) * gran_stride(A.ks0) : A.a0 + (r0_ * A.ks0) * kSlabB;                           \
+    abase1 = A.a1 ? (kTileMajor ? A.a1 + (r0_ >> 7) * gran_stride(A.ks1) : A.a1 + (r0_ * A.ks1) * kSlabB) : abase0;         \
     lrmax = (unsigned)min((int64_t)(RT - 1), A.m - 1 - r0_);                             \
   }
   SDG_TILEBASE()
@@ -143,12 +171,17 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #define SDG_BASES()                                                                                                       \
   const char* wbase = A.wp + (unsigned)ls * kSlabB;                                                                       \
   const bool seg1_ = ls >= A.ks0;                                                                                         \
-  const char* abase = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * kSlabB : abase0 + (unsigned)ls * kSlabB;                  \
-  const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * kSlabB, wstride = (unsigned)ks * kSlabB;                   \
-  const unsigned wrow0 = lb * (unsigned)FP, wrmax = (unsigned)A.n - 1u;
+  const unsigned sstep_ = kTileMajor ? (unsigned)kGranSlab : (unsigned)kSlabB;                                            \
+  const char* abase = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * sstep_ : abase0 + (unsigned)ls * sstep_;                  \
+  const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * sstep_ + (unsigned)kGranPad, wstride = (unsigned)ks * kSlabB; \
+  const unsigned wrow0 = (pbase + lb) * (unsigned)FP, wrmax = (unsigned)A.n - 1u;
+// ray rows of a slab.  Ray-major: row * astride (clamped to the tile's last valid ray).  Tile-major: row = 64 j + (tid >> 3) sits in
+// granule j >> 1 at ((j & 1) 64 + (tid >> 3)) 128 + (tid & 7) 16 = (j & 1) 8192 + 16 tid -- ONE register (t16) plus compile-time and
+// uniform terms; a row beyond the tile's last valid ray reads row 0 of the tile instead (a duplicate of a valid ray, never stored).
 #define SDG_LOAD(J, P)                                                                                                    \
   P = *reinterpret_cast<const uint4*>((J) < kWL ? wbase + (min(wrow0 + 64u * (J) + lrow, wrmax) * wstride + lc16)         \
-                                                : abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));
+      : !kTileMajor ? abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16)                                     \
+      : abase + ((64u * ((J) - kWL) + lrow <= lrmax) ? t16 + (unsigned)((((J) - kWL) & 1) * 8192) + (unsigned)(((J) - kWL) >> 1) * astride : lc16));
 #define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
 #define SDG_WRITE(DST, J, P) *reinterpret_cast<uint4*>((DST) + (J) * 64 * kPRow) = P;
 #define SDG_WRITE_ALL(DST) SDG_WRITE(DST, 0, p0) SDG_WRITE(DST, 1, p1) SDG_WRITE(DST, 2, p2) SDG_WRITE(DST, 3, p3) SDG_WRITE(DST, 4, p4) SDG_WRITE(DST, 5, p5) SDG_WRITE(DST, 6, p6) SDG_WRITE(DST, 7, p7)
@@ -156,13 +189,13 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #define SDG_ADVANCE()                                     \
   if (++ls == ks) {                                       \
     ls = 0;                                               \
-    if (++lb == n_pass) {                                 \
-      if (lt + gridDim.x < total_tiles) {                 \
+    if (++lb == npl) {                                    \
+      if (lt + tstride < total_tiles) {                   \
         lb = 0;                                           \
-        lt += gridDim.x;                                  \
+        lt += tstride;                                    \
         SDG_TILEBASE()                                    \
       } else {                                            \
-        lb = n_pass - 1;                                  \
+        lb = npl - 1;                                     \
       }                                                   \
     }                                                     \
   }
@@ -274,24 +307,32 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
     SDG_T(t1_)
     SDG_ACC(0, t0_, t1_)
     if (last) {     // the pass is complete: its epilogue borrows the stage just consumed (the other one holds the next pass's first slab)
+      // Opaque copies of the thread coordinates for the whole epilogue: formed HERE.  As loop invariants of the (tile, pass, slab) loop
+      // the epilogue's dozens of staging / store addresses were hoisted to the kernel's start, spilled, and partly reloaded inside the
+      // slab loop (tile-major build: 112 spilled registers; with the copies: the epilogue recomputes them, a few dozen VALU per pass).
+      unsigned te = threadIdx.x;
+      asm volatile("" : "+v"(te));
+      const int lane_e = (int)(te & 63u), wave_e = __builtin_amdgcn_readfirstlane((int)(te >> 6));
+      const int wm_e = wave_e >> 1, wn_e = wave_e & 1;
+      const int rayl_e = wn_e * 32 * NTN + (lane_e & 31);
       char* const stg = smem + buf * kWStage;        // staging [128 rays][528 B]: one (128-feature block, 128-ray half) at a time
-      for (int i = tid; i < NTM * RT; i += 512) (&wmaxb[0][0])[i] = 0u;
+      for (int i = te; i < NTM * RT; i += 512) (&wmaxb[0][0])[i] = 0u;
       const bool tile_mode = NTM == 3 && NTN == 2 && A.out_tile_inv != nullptr;       // the one-pass 384 x 128 shape only (compiled out of the other: its register budget is spent)
-      if (tid == 0) tile_max = 0u;
+      if (te == 0) tile_max = 0u;
       __syncthreads();
-      const int f0 = (int)pass * FP;
+      const int f0 = (int)(pbase + pass) * FP;
       typedef float f32x2_t __attribute__((ext_vector_type(2)));
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       const bool planes_out = A.out_f32 == nullptr;
       {
-        // lane: rays rayl + 32 tn, features (of the pass) tm*128 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); acc becomes the layer output in
+        // lane_e: rays rayl_e + 32 tn, features (of the pass) tm*128 + wm_e*32 + 8*(r>>2) + 4*(lane_e>>5) + (r&3); acc becomes the layer output in
         // place.  All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed
         // fp32 multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value.
         const int glast = (ks - 1) >> 2;
         const float relu_floor = A.relu ? 0.f : -__builtin_inff();
         float ib[NTN];
 #pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) ib[tn] = pow2i(-shl[glast][rayl + 32 * tn]);
+        for (int tn = 0; tn < NTN; ++tn) ib[tn] = pow2i(-shl[glast][rayl_e + 32 * tn]);
 #pragma unroll
         for (int tm = 0; tm < NTM; ++tm) {
           float rmax[NTN];
@@ -299,7 +340,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           for (int tn = 0; tn < NTN; ++tn) rmax[tn] = 0.f;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int fl4 = f0 + tm * 128 + wm * 32 + 8 * rg + 4 * (lane >> 5);
+            const int fl4 = f0 + tm * 128 + wm_e * 32 + 8 * rg + 4 * (lane_e >> 5);
             const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + kMaxN + fl4);
             const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
             const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
@@ -321,14 +362,14 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #pragma unroll
             for (int tn = 1; tn < NTN; ++tn) r2 = fmaxf(r2, rmax[tn]);
             r2 = sdg_wave_max(r2);
-            if (lane == 0) atomicMax(&tile_max, __float_as_uint(r2));
+            if (lane_e == 0) atomicMax(&tile_max, __float_as_uint(r2));
           } else if (planes_out) {
-            // per-(block, ray) maximum: the partner lane l ^ 32 holds the wave's other features of the ray, the other three feature waves
+            // per-(block, ray) maximum: the partner lane_e l ^ 32 holds the wave's other features of the ray, the other three feature waves
             // the block's other slabs (LDS maximum on the bit patterns: the values are non-negative)
 #pragma unroll
             for (int tn = 0; tn < NTN; ++tn) {
               const float r2 = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
-              if (lane < 32) atomicMax(&wmaxb[tm][rayl + 32 * tn], __float_as_uint(r2));
+              if (lane_e < 32) atomicMax(&wmaxb[tm][rayl_e + 32 * tn], __float_as_uint(r2));
             }
           }
         }
@@ -340,7 +381,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
         for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < NTN; ++tn) {
-            const int ray = rayl + 32 * tn;
+            const int ray = rayl_e + 32 * tn;
             int sh;
             if (tile_mode) {      // the scale rule of k_split_tiles_f16 (score.hip), on the same fp32 values: identical planes
               const float m = __uint_as_float(tile_max);
@@ -351,10 +392,10 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
                 sh = 14 - e;
                 sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
               }
-              if (tid == 0 && tm == 0 && tn == 0) A.out_tile_inv[ray0 / RT] = ldexpf(1.f, -sh);
+              if (te == 0 && tm == 0 && tn == 0) A.out_tile_inv[ray0 / RT] = ldexpf(1.f, -sh);
             } else {
               sh = p_shift(__uint_as_float(wmaxb[tm][ray]));
-              if (wm == 0 && lane < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + tm] = sh;
+              if (wm_e == 0 && lane_e < 32 && ray0 + ray < A.m) A.out_shift[(ray0 + ray) * nb_all + (f0 >> 7) + tm] = sh;
             }
             const float sc = tile_mode ? ldexpf(1.f, sh) : pow2i(sh);
 #pragma unroll
@@ -378,23 +419,23 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #pragma unroll
       for (int tm = 0; tm < NTM; ++tm) {                    // unit = (128-feature block tm, 128-ray half): its waves fill the staging tile
         for (int hsel = 0; hsel < RT / 128; ++hsel) {
-          if (((wn * 32 * NTN) >> 7) == hsel) {
-            const int ru = (rayl & 127);                    // ray within the unit: ru + 32 * tn
+          if (((wn_e * 32 * NTN) >> 7) == hsel) {
+            const int ru = (rayl_e & 127);                    // ray within the unit: ru + 32 * tn
             if (!planes_out) {
               float* st = reinterpret_cast<float*>(stg);
 #pragma unroll
               for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                  *reinterpret_cast<float4*>(st + (ru + 32 * tn) * (kStRow / 4) + wm * 32 + 8 * rg + 4 * (lane >> 5)) =
+                  *reinterpret_cast<float4*>(st + (ru + 32 * tn) * (kStRow / 4) + wm_e * 32 + 8 * rg + 4 * (lane_e >> 5)) =
                       float4{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1], acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
             } else {
 #pragma unroll
               for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                  // feature wm*32 + 8 rg + 4 (lane>>5) + j of the block: slab wm, position 8 rg + 4 (lane>>5)
-                  char* d = stg + (ru + 32 * tn) * kStRow + wm * kSlabB + (8 * rg + 4 * (lane >> 5)) * 2;
+                  // feature wm_e*32 + 8 rg + 4 (lane_e>>5) + j of the block: slab wm_e, position 8 rg + 4 (lane_e>>5)
+                  char* d = stg + (ru + 32 * tn) * kStRow + wm_e * kSlabB + (8 * rg + 4 * (lane_e >> 5)) * 2;
                   *reinterpret_cast<f32x2_t*>(d) = f32x2_t{acc[tm][tn][4 * rg], acc[tm][tn][4 * rg + 1]};
                   *reinterpret_cast<f32x2_t*>(d + 64) = f32x2_t{acc[tm][tn][4 * rg + 2], acc[tm][tn][4 * rg + 3]};
                 }
@@ -405,28 +446,39 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           const int64_t rbase = ray0 + hsel * 128;
           if (!planes_out) {
 #pragma unroll
-            for (int i = tid; i < 128 * 32; i += 512) {
+            for (int i = (int)te; i < 128 * 32; i += 512) {
               const int ray = i >> 5, c = i & 31;
               if (rbase + ray < A.m)
                 *reinterpret_cast<float4*>(A.out_f32 + (rbase + ray) * A.ldo + fb + c * 4) = reinterpret_cast<const float4*>(stg + ray * kStRow)[c];
             }
-          } else {
+          } else if (!kTileMajor || tile_mode) {      // ray-major rows: the scorer's key planes [ray][12 slabs][128 B] (and the round-2 layout)
             const int nslab_out = A.n >> 5;
 #pragma unroll
-            for (int i = tid; i < 128 * 32; i += 512) {
+            for (int i = (int)te; i < 128 * 32; i += 512) {
               const int ray = i >> 5, c = i & 31;
               if (rbase + ray < A.m)
                 *reinterpret_cast<uint4*>(A.out_planes + ((rbase + ray) * nslab_out + (fb >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stg + ray * kStRow)[c];
             }
+          } else {
+            // tile-major: the unit's four slabs are 4 x 16 KB of CONSECUTIVE bytes; thread t moves bytes [16 t + 8192 it, + 16) of them for
+            // it = 0 .. 7: slab it >> 1, ray (t >> 3) + 64 (it & 1), chunk t & 7 of the staged tile
+            const int nslab_out = A.n >> 5;
+            char* const gb = A.out_planes + (rbase >> 7) * gran_stride(nslab_out) + (fb >> 5) * (int64_t)kGranSlab + te * 16u;
+            const char* const sb = stg + (te >> 3) * kStRow + (te & 7u) * 16;
+            const int64_t left = A.m - rbase - (te >> 3);      // this thread's rays (t >> 3) and (t >> 3) + 64 exist while left > 0 / > 64
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+              if (left > 64 * (it & 1))
+                *reinterpret_cast<uint4*>(gb + it * 8192) = *reinterpret_cast<const uint4*>(sb + (it & 1) * 64 * kStRow + (it >> 1) * kSlabB);
           }
           __syncthreads();
         }
       }
       SDG_T(te_)
       SDG_ACC(1, t1_, te_)
-      if (++pass == n_pass) {      // next tile of this workgroup
+      if (++pass == npl) {      // next tile of this workgroup
         pass = 0;
-        tile += gridDim.x;
+        tile += tstride;
         if (tile >= total_tiles) break;
         ray0 = (int64_t)tile * RT;
         SDG_SHIFT_FETCH()
@@ -513,7 +565,9 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
       h[e] = hh;
       l[e] = (_Float16)(x - (float)hh);
     }
-    char* dst = xp + ((ray0 + r) * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
+    const int64_t gr = ray0 + r;
+    char* dst = kTileMajor ? xp + (gr >> 7) * gran_stride(5) + (((g8 >> 2)) * kGran + (gr & 127)) * kSlabB + (g8 & 3) * 16
+                           : xp + (gr * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
     *reinterpret_cast<f16x8_t*>(dst) = h;
     *reinterpret_cast<f16x8_t*>(dst + 64) = l;
     if (g8 == 0) { xs[2 * (ray0 + r)] = sh; xs[2 * (ray0 + r) + 1] = sh; }
@@ -542,6 +596,8 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
   *reinterpret_cast<f16x8_t*>(d + 64) = l;
 }
 
+bool g_dense_no_split = getenv("SIXDGS_DENSE_NO_SPLIT") != nullptr;      // developer switch: the round-2 form (both passes in one workgroup)
+
 int dense_grid(int64_t tiles) {
   static int cus = 0;      // one persistent workgroup per compute unit (the kernel's 156 KB of LDS allow one)
   if (cus == 0) {
@@ -562,10 +618,13 @@ int launch_dense(const DenseArgs& A, hipStream_t s) {
   if (!wide && A.n % 256 != 0) return SIXDGS_E_BADARG;
   const int64_t tiles = sdg_cdiv(A.m, wide ? 128 : 256);
   if (tiles > 0x7fffffffLL) return SIXDGS_E_BADARG;
-  const int grid = dense_grid(tiles);
+  const unsigned n_pass = (unsigned)(wide ? A.n / 384 : A.n / 256);
+  const unsigned split = (!wide && n_pass == 2 && !g_dense_no_split) ? 1u : 0u;
+  int grid = dense_grid(split ? 2 * tiles : tiles);
   if (grid <= 0) return (int)hipErrorInvalidDevice;
-  if (wide) hipLaunchKernelGGL((k_dense_planes<3, 2>), dim3((unsigned)grid), dim3(512), 0, s, A, (unsigned)(A.n / 384), (unsigned)tiles);
-  else hipLaunchKernelGGL((k_dense_planes<2, 4>), dim3((unsigned)grid), dim3(512), 0, s, A, (unsigned)(A.n / 256), (unsigned)tiles);
+  if (split) grid &= ~1;                       // sibling pairs
+  if (wide) hipLaunchKernelGGL((k_dense_planes<3, 2>), dim3((unsigned)grid), dim3(512), 0, s, A, n_pass, (unsigned)tiles, 0u);
+  else hipLaunchKernelGGL((k_dense_planes<2, 4>), dim3((unsigned)grid), dim3(512), 0, s, A, n_pass, (unsigned)tiles, split);
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -599,17 +658,19 @@ int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipSt
   return 0;
 }
 
-size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 4 + 4) * sizeof(int); }
+size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 4 + 4) * sizeof(int) + (3 * (size_t)kGranPad + kGran - 1) / kGran; }
 
-// ori/dir/rgb of m rays -> fp32 keys kdst [m][384] (row stride 384).  ws: dense_chain_bytes_per_ray() * m bytes, 256-B aligned.
+// ori/dir/rgb of m rays -> fp32 keys kdst [m][384] (row stride 384).  ws: dense_chain_bytes_per_ray() * (m rounded up to 128) bytes, 256-B aligned.
 int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* kplanes,
                 float* kinv, char* ws, hipStream_t s) {
+  const size_t mp = (size_t)sdg_cdiv(m, kGran) * kGran;      // the plane buffers hold whole granules of 128 rays (tile-major layout)
+  const size_t ng = mp / kGran;
   char* xp = ws;
-  char* hp1 = xp + (size_t)m * 5 * kSlabB;
-  char* hp2 = hp1 + (size_t)m * 16 * kSlabB;
-  int* xs = reinterpret_cast<int*>(hp2 + (size_t)m * 16 * kSlabB);
-  int* sa = xs + 2 * m;
-  int* sb = sa + 4 * m;
+  char* hp1 = xp + ng * (size_t)(5 * kGranSlab + kGranPad);
+  char* hp2 = hp1 + ng * (size_t)(16 * kGranSlab + kGranPad);
+  int* xs = reinterpret_cast<int*>(hp2 + ng * (size_t)(16 * kGranSlab + kGranPad));
+  int* sa = xs + 2 * mp;
+  int* sb = sa + 4 * mp;
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
                ok = o4 + (size_t)384 * 16 * kSlabB;
   hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);

@@ -310,7 +310,8 @@ constexpr size_t kPackedFloats = kOffPlanes + pad64(kPlaneFloats);
 
 // per ray of a chunk: fp32-operand chain x, h1, h2 + three row-maximum arrays = 1171 floats; plane-to-plane chain fp32 keys (384 floats)
 // + planes and shifts (4776 B): the larger of the two
-constexpr size_t kChunkFloatsPerRay = 1580;
+constexpr size_t kChunkFloatsPerRay = 1640;      // 1536 B of fp32 keys + dense_chain_bytes_per_ray() (asserted in sixdgs_ray_keys_ex)
+constexpr int64_t kChunkSlackRays = 128;      // the plane-to-plane chain keeps whole granules of 128 rays: a ragged last chunk rounds up
 
 }  // namespace
 
@@ -429,7 +430,7 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
   if (max_chunk <= 0) max_chunk = 262144;
   int64_t c = r < max_chunk ? r : max_chunk;
   if (c < 1) c = 1;
-  return sdg_align((size_t)c * kChunkFloatsPerRay * sizeof(float));
+  return sdg_align((size_t)(c + kChunkSlackRays) * kChunkFloatsPerRay * sizeof(float));
 }
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
@@ -445,7 +446,8 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
   const bool f16 = key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32 || mma_mode == SIXDGS_MMA_DEFAULT);
   SDG_CHECK_ARG(!f16 || key_inv_scale);
-  const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float)));
+  if (kChunkFloatsPerRay * sizeof(float) < (size_t)SIXDGS_D * sizeof(float) + dense_chain_bytes_per_ray()) return SIXDGS_E_WORKSPACE;
+  const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float))) - kChunkSlackRays;
   if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;
   const int64_t chunk = chunk_cap < r ? (chunk_cap >= 128 ? chunk_cap / 128 * 128 : chunk_cap) : r;
   if (f16 && chunk < r && (chunk % 128) != 0) return SIXDGS_E_WORKSPACE;   // scale tiles must not straddle chunks

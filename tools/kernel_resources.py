@@ -6,7 +6,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 out = os.path.join(ROOT, "gpurun_out", "asm")
 os.makedirs(out, exist_ok=True)
 asm = os.path.join(out, os.path.basename(src) + ".s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *os.environ.get("SIXDGS_EXTRA_FLAGS", "").split(), "-S", "--cuda-device-only",
                        "-o", asm, src], stderr=subprocess.DEVNULL)
 t = open(asm).read()
 g = lambda blk, k: re.search(r"\." + k + r":\s+(\d+)", blk).group(1)

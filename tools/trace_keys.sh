@@ -1,8 +1,9 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2l; mkdir -p $O
+# per-layer times of the plane-to-plane chain from a rocprofv3 kernel trace:  bash tools/trace_keys.sh <out-name>   (SIXDGS_LIB selects a variant)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-trace_keys}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $R/tools/time_keys.py 4194304 > $O/time_keys.log 2> $O/trace.err
 DB=$(find $O/trace -name "*.db" | head -1)
-python - <<PY
+python - <<PY | tee $O/layers.txt
 import sqlite3
 db=sqlite3.connect("$DB"); cur=db.cursor()
 rows=list(cur.execute("select name, grid_x, count(*), avg(duration), sum(duration) from kernels where name like '%k_dense%' or name like '%k_ray_encode%' or name like '%k_split_tiles%' or name like '%k_linear%' group by name, grid_x order by sum(duration) desc"))
