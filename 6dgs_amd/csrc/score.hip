@@ -746,7 +746,8 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
           const int t128 = min(2 * tile + wn, n_tiles128 - 1);
           const float cfl = ((cq * load_uniform(A.kinv + t128)) * kInvSqrtD) * 1.4426950408889634f;
           const bool ragged = lim_cur < kBNX - 1;
-          const int ray0 = wn * 128 + 4 * (lane >> 5);
+          int ray0 = wn * 128 + 4 * (lane >> 5);
+          asm volatile("" : "+v"(ray0));        // formed here, not hoisted (see the two-pass branch below)
           const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8, lb4 = lane & 16;
           float fin[4];
 #pragma unroll
@@ -852,7 +853,10 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) sum[r & 3] += __expf(acc[tm][tn][r] - mn);
           } else {
-            const int ray0 = wn * 128 + 4 * (lane >> 5);
+            // (only the scene's last tile comes here.  The 64 ray indices are formed from an OPAQUE copy: as loop invariants they were
+            // hoisted to the kernel's start and spilled -- 344 B of scratch in round 2 -- for a branch taken once per launch)
+            int ray0 = wn * 128 + 4 * (lane >> 5);
+            asm volatile("" : "+v"(ray0));
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll

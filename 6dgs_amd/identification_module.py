@@ -235,40 +235,67 @@ class IdentificationModule(torch.nn.Module):
     @torch.no_grad()
     def score_tokens(self, token_list: List[torch.Tensor], rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100,
                      want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
-                     profile=None):
-        """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None."""
+                     profile=None, defer_status: bool = False):
+        """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None.
+
+        defer_status (select path only): do NOT read the per-image status on the host here -- the call then enqueues work and
+        nothing else (capturable in a hipGraph, no sync in the middle of a step) and leaves `self.pending_select`; the caller
+        reads the status together with its own results (one D2H per batch) and calls `finish_select` if any image was refused."""
         kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
         q, n_tok, n_host = self._tokens_to_q(token_list, rays_ori.device)
         self.last_scoring_path = "two-pass"
+        self.pending_select = None
+        capturing = torch.cuda.is_current_stream_capturing()
         if (not want_scores and kc.get("sample") is not None and ops.select_enabled() and ops.effective_mma_mode() in ops.F16_MODES
-                and rays_to_output <= ops.SELECT_MAX_CANDIDATES and not torch.cuda.is_current_stream_capturing()):
+                and rays_to_output <= ops.SELECT_MAX_CANDIDATES and (defer_status or not capturing)):
             # inference: only the top-k is wanted -> no logits through HBM (sixdgs_score_select); images the bounds cannot decide
             # (status -1: too many near-ties for max_candidates, or an exponent overflow) go through the two-pass scorer below
             b, r = q.shape[0], rays_ori.shape[0]
             need = ops.score_select_workspace_bytes(r, b, rays_to_output, ops.SELECT_MAX_CANDIDATES)
             sw = getattr(self, "_select_ws", None)
             if sw is None or sw.numel() < need or sw.device != q.device:
+                if capturing:
+                    raise RuntimeError("6dgs_amd: the select workspace must exist before a hipGraph capture (run the batch once eagerly)")
                 self._select_ws = sw = None
                 self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
             idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
                                                 max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
                                                 key_norm=kc["norm"])
-            st = status.tolist()                       # the one host sync of the path (B ints)
-            self.last_select_candidates = st
-            redo = [i for i, v in enumerate(st) if v < 0]
-            self.last_scoring_path = "select" if not redo else f"select+two-pass({len(redo)})"
-            if redo:
-                sel = torch.tensor(redo, device=q.device)
-                i2, v2, _, _ = ops.score_topk(q[sel].contiguous(), n_tok[sel].contiguous(), kc["key"], rays_to_output, want_scores=False,
-                                              workspace=workspace, images_in_flight=images_in_flight, key_planes=kc["planes"],
-                                              key_scale=kc["scale"])
-                idx[sel], val[sel] = i2, v2
+            self.last_scoring_path = "select"
+            pend = dict(status=status, q=q, n_tok=n_tok, k=rays_to_output, workspace=workspace, images_in_flight=images_in_flight,
+                        rays=(rays_ori, rays_dir, rays_rgb))
+            if defer_status:
+                self.pending_select = pend
+                return idx, val, None
+            idx, val, _ = self.finish_select(idx, val, pend)
             return idx, val, None
         idx, val, scores, _ = ops.score_topk(q, n_tok, kc["key"], rays_to_output, want_scores=want_scores, workspace=workspace,
                                              images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
                                              key_planes=kc["planes"], key_scale=kc["scale"])
         return idx, val, scores
+
+    @torch.no_grad()
+    def finish_select(self, idx, val, pending=None, status_host=None):
+        """Second half of a select-path call: read the statuses (unless the caller already has them on the host) and score the refused
+        images with the two-pass scorer.  Returns (idx, val, refused image numbers); idx / val are updated in place."""
+        pend = pending if pending is not None else self.pending_select
+        self.pending_select = None
+        if pend is None:
+            return idx, val, []
+        st = pend["status"].tolist() if status_host is None else [int(v) for v in status_host]      # the one host sync of the path (B ints)
+        self.last_select_candidates = st
+        redo = [i for i, v in enumerate(st) if v < 0]
+        self.last_scoring_path = "select" if not redo else f"select+two-pass({len(redo)})"
+        if redo:
+            kc = self._ensure_keys(*pend["rays"])
+            q, n_tok = pend["q"], pend["n_tok"]
+            sel = torch.tensor(redo, device=q.device)
+            i2, v2, _, _ = ops.score_topk(q[sel].contiguous(), n_tok[sel].contiguous(), kc["key"], pend["k"], want_scores=False,
+                                          workspace=pend["workspace"], images_in_flight=pend["images_in_flight"], key_planes=kc["planes"],
+                                          key_scale=kc["scale"])
+            idx[sel], val[sel] = i2, v2
+        return idx, val, redo
 
     @torch.no_grad()
     def score_tokens_ray_sharded(self, token_list, rays_ori, rays_dir, rays_rgb, ray_offset: int, r_total: int, rays_to_output: int = 100,

@@ -78,14 +78,14 @@ def prepare_images_device(images):
 
 class _ImageSideGraph:
     """hipGraph of the image side of a batch (uint8 -> fp32, resize / crop / normalise, ViT-S/14, token assembly, camera-up
-    CNN): ~250 small launches that are launch-bound at 4..16 images.  One graph per (module weights, batch shape); inputs are
+    CNN): ~250 small launches that are launch-bound at 1..16 images.  One graph per (module weights, batch shape); inputs are
     copied into a static buffer, outputs are static tensors consumed in stream order before the next replay."""
 
     def __init__(self):
         self.key, self.graph, self.inp, self.out, self.failed = None, None, None, None, False
 
     def run(self, id_module, images):
-        if self.failed or len(images) < 2 or not all(im.shape == images[0].shape and im.shape[-1] == 3 and im.dtype == torch.uint8 for im in images):
+        if self.failed or len(images) < 1 or not all(im.shape == images[0].shape and im.shape[-1] == 3 and im.dtype == torch.uint8 for im in images):
             return None
         key = (len(images), tuple(images[0].shape), str(images[0].device), next(id_module.parameters()).data_ptr(),
                tuple(p._version for p in id_module.parameters()))
@@ -127,12 +127,16 @@ def prime_image_graph(id_module, images) -> bool:
 @torch.no_grad()
 def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None, k: int = 100, workspace=None,
                    images_in_flight=None, profile=None, tokens=None, up=None, want_scores: bool = False, image_graph: bool = True,
-                   streamed_chunk_rays: Optional[int] = None):
+                   streamed_chunk_rays: Optional[int] = None, defer_status: bool = False):
     """One batch of the hot path: query images (uint8 [H,W,3|4] tensors on the GPU) -> poses.
     image prep -> backbone tokens + camera-up (PyTorch-ROCm) -> q_proj / scorer / top-k / pose solve (HIP).
     `tokens` / `up` inject the image-side boundary inputs instead.  Everything is enqueued on the current
     stream; nothing syncs until the caller reads the returned device tensors.  `streamed_chunk_rays` selects the
-    streamed scorer (IdentificationModule.score_tokens_streamed) with that chunk size."""
+    streamed scorer (IdentificationModule.score_tokens_streamed) with that chunk size.
+
+    defer_status: the select path's per-image status is not read inside (no sync in the middle of the batch: the whole call is
+    one capturable stream of launches); the result then carries `packed` = [c2w (16) | select status] per image -- ONE D2H for
+    the caller -- and `resolve_poses(id_module, sol, packed_host)` re-does the images the select path refused (rare)."""
     if tokens is None:
         res = None
         if image_graph and not torch.cuda.is_current_stream_capturing():
@@ -150,10 +154,37 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
         scores = None
     else:
         idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
-                                                      workspace=workspace, images_in_flight=images_in_flight, profile=profile)
+                                                      workspace=workspace, images_in_flight=images_in_flight, profile=profile,
+                                                      defer_status=defer_status)
     sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt_c2w)
     sol.update(idx=idx, weights=weights, scores=scores, tokens=tokens, up=up)
+    if defer_status:
+        pend = getattr(id_module, "pending_select", None)
+        st = pend["status"].to(torch.float32) if pend is not None else torch.zeros(idx.shape[0], device=idx.device)
+        sol["packed"] = torch.cat([sol["c2w"].reshape(-1, 16), st[:, None]], dim=1)
+        sol["pending_select"] = pend
+        sol["_inputs"] = (rays_ori, rays_dirs, gt_c2w)
     return sol
+
+
+@torch.no_grad()
+def resolve_poses(id_module, sol, packed_host):
+    """After the one D2H of a defer_status batch: c2w [B,4,4] on the host; images whose select status is negative (the bounds could
+    not decide them) are scored by the two-pass scorer and solved again -- eagerly, outside any graph."""
+    c2w = packed_host[:, :16].reshape(-1, 4, 4).clone()
+    pend = sol.get("pending_select")
+    if pend is None:
+        return c2w
+    status = packed_host[:, 16].round().to(torch.int64).tolist()
+    if min(status) >= 0:
+        id_module.last_select_candidates = status
+        return c2w
+    idx, weights = sol["idx"].clone(), sol["weights"].clone()
+    idx, weights, redo = id_module.finish_select(idx, weights, pend, status_host=status)
+    rays_ori, rays_dirs, gt = sol["_inputs"]
+    again = ops.solve_pose(rays_ori, rays_dirs, idx, weights, sol["up"], gt)
+    sol.update(again, idx=idx, weights=weights)
+    return again["c2w"].cpu()
 
 
 @torch.no_grad()

@@ -272,3 +272,64 @@ def test_select_near_ties_at_the_threshold_with_large_logits(ops):
         assert float(s[idx[b]].min()) >= float(s[o[99]]) * (1.0 - tie)
         assert float(((val[b].double() - s[idx[b]]).abs() / s[o[0]]).max()) < tie
         assert float((val[b] - sc[b][idx[b]]).abs().max() / v2[b][0]) < tie          # and the two-pass scorer agrees on those rays
+
+
+def test_deferred_status_whole_step_graph_and_resolve(ops, syn):
+    """the select path's one host read (B status ints) deferred to the step's own D2H, so that image side + q_proj +
+    select + pose solve capture into ONE hipGraph.  (a) deferred == immediate; (b) a captured step replayed on NEW images gives the
+    eager poses of those images; (c) images the select path refuses (forced: room for 104 candidates under a flat softmax) are re-done
+    by resolve_poses with the two-pass scorer's answer."""
+    pkg = importlib.import_module("6dgs_amd")
+    tp = importlib.import_module("6dgs_amd.test")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+    idm = idm.cuda().eval()
+    rays = syn.make_rays(1_200_000, 3)
+    o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+
+    def batch(seed):
+        return [torch.from_numpy(np.ascontiguousarray(cam["image"])).cuda() for cam in syn.make_cameras(2, seed, width=160, height=120)]
+
+    imgs = batch(50)
+    eager = tp.estimate_poses(idm, imgs, o, d, c)
+    assert idm.last_scoring_path == "select"
+    sol = tp.estimate_poses(idm, imgs, o, d, c, defer_status=True)
+    assert sol["packed"].shape == (2, 17) and sol["pending_select"] is not None
+    c2w = tp.resolve_poses(idm, sol, sol["packed"].cpu())
+    assert torch.equal(c2w, eager["c2w"].cpu()) and torch.equal(sol["idx"], eager["idx"]) and min(idm.last_select_candidates) >= 100
+    # (b) one hipGraph for the whole step
+    static = [im.clone() for im in imgs]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tp.estimate_poses(idm, static, o, d, c, defer_status=True, image_graph=False)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gsol = tp.estimate_poses(idm, static, o, d, c, defer_status=True, image_graph=False)
+    for seed in (51, 52):
+        new = batch(seed)
+        for s_, n_ in zip(static, new):
+            s_.copy_(n_)
+        g.replay()
+        got = tp.resolve_poses(idm, gsol, gsol["packed"].cpu())
+        want = tp.estimate_poses(idm, new, o, d, c, image_graph=False)
+        assert torch.equal(gsol["idx"], want["idx"]), seed
+        assert float((got - want["c2w"].cpu()).abs().max()) < 1e-6
+    # (c) refused images
+    flat = [t * 0.0005 for t in (torch.from_numpy(syn.make_tokens(256, 60 + i, 40.0)).cuda() for i in range(2))]
+    up = torch.nn.functional.normalize(torch.tensor([[0.1, 0.9, 0.2], [0.3, -0.5, 0.8]], device="cuda"), dim=-1)
+    ref = tp.estimate_poses(idm, None, o, d, c, tokens=flat, up=up, want_scores=True)          # two-pass scorer
+    old = ops.SELECT_MAX_CANDIDATES
+    try:
+        ops.SELECT_MAX_CANDIDATES = 104
+        idm._select_ws = None
+        sol = tp.estimate_poses(idm, None, o, d, c, tokens=flat, up=up, defer_status=True)
+        host = sol["packed"].cpu()
+        assert host[:, 16].tolist() == [-1.0, -1.0]
+        c2w = tp.resolve_poses(idm, sol, host)
+    finally:
+        ops.SELECT_MAX_CANDIDATES = old
+        idm._select_ws = None
+    assert idm.last_scoring_path == "select+two-pass(2)"
+    assert torch.equal(sol["idx"], ref["idx"]) and float((c2w - ref["c2w"].cpu()).abs().max()) < 1e-6
