@@ -746,8 +746,12 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
           const int t128 = min(2 * tile + wn, n_tiles128 - 1);
           const float cfl = ((cq * load_uniform(A.kinv + t128)) * kInvSqrtD) * 1.4426950408889634f;
           const bool ragged = lim_cur < kBNX - 1;
+#ifdef SDG_UB_OPAQUE
           int ray0 = wn * 128 + 4 * (lane >> 5);
           asm volatile("" : "+v"(ray0));        // formed here, not hoisted (see the two-pass branch below)
+#else
+          const int ray0 = wn * 128 + 4 * (lane >> 5);
+#endif
           const bool lb0 = lane & 1, lb1 = lane & 2, lb2 = lane & 4, lb3 = lane & 8, lb4 = lane & 16;
           float fin[4];
 #pragma unroll

@@ -86,7 +86,6 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole per-batch path (image prep, ViT, CNN, scorer, pose solve) in one hipGraph and replay it "
                          "per step: for the launch-bound small-scene regime (--mode reference); kernel timing needs the eager path")
-    ap.add_argument("--no-graph", action="store_true", help="never capture the step in a hipGraph (default: captured when --batch <= 2, the latency regime)")
     ap.add_argument("--no-select", action="store_true",
                     help="score with the two-pass scorer (logits through HBM) instead of the select path (top-k without materialised logits)")
     ap.add_argument("--l32-steps", type=int, default=-1,
@@ -165,10 +164,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     ray_sharded = args.parallelism == "ray"
-    # The whole per-batch path (image side, q_proj, select path with its status read deferred to the step's one D2H, pose solve) is
-    # one capturable stream of launches.  At 1-2 images per step the ~300 launches are a tenth of the step: replay it as ONE hipGraph.
-    if not args.graph and not args.no_graph and args.batch <= 2 and args.scoring != "streamed" and not ray_sharded and args.mode == "full":
-        args.graph = True
+    # (--graph: the whole per-batch path -- image side, q_proj, select path with its status read deferred to the step's one D2H, pose
+    # solve -- replayed as ONE hipGraph.  Measured in round 3 at 1 image per step: 26.4 ms against 13.9 ms eager with the image side alone
+    # as a graph -- replaying the scorer's ~60 nodes costs more than launching them -- so it stays opt-in.)
     if ray_sharded and args.mode != "full":
         raise SystemExit("--parallelism ray needs --mode full")
     if ray_sharded:
@@ -240,7 +238,7 @@ def main():
         if ray_sharded:
             return tp.estimate_poses_ray_sharded(idm, images, ori, dr, rgb, ray_offset, R_total, gt_c2w=gts, profile=p)
         return tp.estimate_poses(idm, images, ori, dr, rgb, gt_c2w=gts, workspace=ws, profile=p,
-                                 streamed_chunk_rays=args.chunk_rays if streamed else None, defer_status=bool(args.graph))
+                                 streamed_chunk_rays=args.chunk_rays if streamed else None, defer_status=bool(args.graph) or use_select)
 
     def step(p):
         if graph is not None:
