@@ -15,6 +15,7 @@
 // default kernel got its shape and what bounds it.
 #include <stdlib.h>
 
+#include <cstdlib>
 #include "gemm_kernel.h"
 
 using namespace sdg;
@@ -468,6 +469,10 @@ struct LogitsF16Args {
   const float* ctok;     // [B][256] per-token exponent offset: -ref_t log2e - log2(f Z~_t), -inf for tokens >= n_tok
   float* ub;             // [nb][4 token quarters wm][ub_stride] partial upper-bound sums of every ray
   int64_t ub_stride;
+  // sibling lock-step (round 3; 0 / null = off): the grid is n_sets x nb PERSISTENT workgroups, sibling set s = the nb workgroups that
+  // score the nb images of a launch against the same ray-tile groups s, s + n_sets, ...; after every tile they meet at sib_sync[s]
+  int n_sets;
+  unsigned* sib_sync;    // [n_sets] zeroed before the launch
 };
 // what the kernel leaves behind for each tile
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
@@ -512,6 +517,15 @@ __device__ unsigned long long g_dbg_cycles[8][8];   // [wave][phase] summed over
 //   are issued in step 3, after the slab barrier.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBNX = 256;                // rays per tile
+// How the select sweep's grid is laid out when a launch scores several images (SIXDGS_SIBLING_SYNC overrides):
+//   0  one-shot grid, one workgroup per (ray-tile group, image) -- round 2.  Workgroups start whenever a CU frees up, the nb siblings of
+//      a group drift apart and re-read key tiles that already left the XCD's 4 MB L2: 1.40x the algorithmic bytes (57.77 ms per launch);
+//   2  PERSISTENT sibling sets (default): n_sets = CUs / nb sets of nb workgroups, all resident from the start, set s walks the groups
+//      s, s + n_sets, ... -- the siblings start every group together: 1.10x (58.16 ms, +0.7 %: static instead of dynamic balancing);
+//   1  the same plus a lock-step after every tile (an atomic arrival + a scalar-load spin per sibling set): 1.05x (58.69 ms, +1.6 %).
+// Measured on the headline workload, `tools/sib_ab.sh`, profiles/r03_pmc_sibling_sets.md.  The re-reads never cost time (the kernel is
+// matrix-pipe / power bound at 1.2 TB/s); the default takes the traffic down where it is free.
+constexpr int kSiblingSyncDefault = 2;
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
 // for that token in this tile).  0.766 x the bytes of fp32 logits, written once and read once per image.
@@ -522,12 +536,13 @@ constexpr int kLdsX = kKBaseX + 6 * kQStageX;   // 160 KiB
 
 // OUT: what leaves the kernel (kOut*): fp32 or 24-bit fixed-point logits (see kTileBytes24), statistics only, or the
 // upper-bound column sums of the select path
-template <int ABL, int OUT>
+template <int ABL, int OUT, bool PERS = false>
 __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   constexpr bool L24 = OUT == kOutL24;
   __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bl = (int)(w % (unsigned)A.nb), grp = (int)(w / (unsigned)A.nb);
+  const int bl = (int)(w % (unsigned)A.nb);
+  const int set = (int)(w / (unsigned)A.nb);        // the ray-tile group (one-shot grid) or the sibling set (persistent grid)
   const int b = A.b0 + bl;
   const int M = A.n_tok[b];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -535,18 +550,26 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   const int wm = wave >> 1, wn = wave & 1;
   const float cq = A.qinv[2 * b + (wm >> 1)];
   const bool active = wm * 64 < M;
-  float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
-  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
-  float ct[2] = {0.f, 0.f}, zs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float ct[2] = {0.f, 0.f};
   if (OUT == kOutUB) {
     ct[0] = A.ctok[(int64_t)b * kT + wm * 64 + (lane & 31)];
     ct[1] = A.ctok[(int64_t)b * kT + wm * 64 + 32 + (lane & 31)];
   }
   // A.n_tiles counts 256-ray tiles here; the groups take floor(n_tiles / n_groups) tiles, the first n_tiles % n_groups one more
   const int t_base = A.n_tiles / A.n_groups, t_rem = A.n_tiles - t_base * A.n_groups;
+  const int n_tiles128 = (int)((A.r + 127) >> 7);
+  unsigned sib_target = 0;                          // arrivals at sib_sync[set] after the tiles walked so far (nb per tile)
+  int grp = set;
+  do {                                              // PERS: the ray-tile groups set, set + n_sets, ...; otherwise the one group `set`
+  float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
+  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  float zs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const int t_begin = grp * t_base + min(grp, t_rem);
   const int t_end = t_begin + t_base + (grp < t_rem ? 1 : 0);
-  const int n_tiles128 = (int)((A.r + 127) >> 7);
+  if (PERS && !(M > 0) && A.sib_sync && t_begin < t_end) {      // an image without tokens walks no tiles: its arrivals all at once
+    if (tid == 0) atomicAdd(A.sib_sync + set, (unsigned)(t_end - t_begin));
+    sib_target += (unsigned)(A.nb * (t_end - t_begin));
+  }
   if (M > 0 && t_begin < t_end) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     // ---- DMA pieces: 1 KiB = 8 rows x 128 B = the two 64-byte planes of a (row, slab), i.e. 8 FULL 128-byte lines per
@@ -720,6 +743,24 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
         if (ABL & 2048) tstamp(4);
       }
 
+      // ---- sibling lock-step: the nb workgroups of this sibling set (same XCD: consecutive work items of the remap) meet here after
+      // every tile, so that they stay within a tile of each other and the key slabs one of them pulls from HBM are still in the XCD's
+      // L2 when the others ask for them (round 2 measured 1.40x the algorithmic bytes: the siblings started together and drifted).
+      // Wave 0 announces (one atomic without return) and spins on a SCALAR load (lgkmcnt: the ring's vmcnt bookkeeping is untouched); the
+      // other waves run on into the epilogue and the next tile's first slab, where the slab barrier holds them for wave 0.
+      if (PERS && A.sib_sync != nullptr) {
+        sib_target += (unsigned)A.nb;
+        if (wave == 0) {
+          unsigned* const sp = A.sib_sync + set;
+          if (lane == 0) __hip_atomic_fetch_add(sp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (true) {
+            unsigned seen;
+            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sp) : "memory");
+            if ((int)(seen - sib_target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
       if (ABL & 2) {
         float sacc = 0.f;
 #pragma unroll
@@ -913,6 +954,8 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     pout[2 * tid] = m;
     pout[2 * tid + 1] = sres;
   }
+  if (PERS) __syncthreads();      // the merge buffer is the ring: done with it before the next group's prologue refills it
+  } while (PERS && (grp += A.n_sets) < A.n_groups);
 }
 
 // fp32 rows [rows][384] (row stride ld) -> fp16 planes [row][12][2][32] of x * 2^s, one power-of-two scale per 128-row
@@ -2019,6 +2062,26 @@ int f16x_groups(int64_t r) {
   return g;
 }
 
+// CUs to spread persistent sibling sets over, or 0 = one-shot grid (SIXDGS_SIBLING_SYNC=0/1 overrides the default)
+int sibling_sync_mode() {      // 0 one-shot grid, 1 persistent sibling sets in lock-step, 2 persistent without the lock-step (measurement)
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SIXDGS_SIBLING_SYNC");
+    mode = e ? atoi(e) : kSiblingSyncDefault;
+  }
+  return mode;
+}
+int sibling_sync_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    const bool on = sibling_sync_mode() != 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (on && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 0;
+  }
+  return cus;
+}
+
 // scaled fp16 planes of q (one power-of-two scale per 128-token half) for images [0, nb)
 void select_q_planes(const float* q, int nb, const SelectWs& w, hipStream_t s) {
   hipLaunchKernelGGL(k_split_tiles_f16, dim3((unsigned)(2 * nb)), dim3(256), 0, s, q, (int64_t)nb * kT, (int64_t)SIXDGS_D, w.qplanes, w.qinv);
@@ -2107,8 +2170,18 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
   for (int i = 0; i < batch; ++i) tok += h_n_tok ? (double)h_n_tok[i] : (double)kT;
   {
     // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
+    unsigned grid = (unsigned)(V.n_groups * batch);
+    const int cus = sibling_sync_cus();
+    if (cus > 0 && batch >= 2 && cus / batch >= 1 && w.p.topk_bytes >= (size_t)(cus / batch) * sizeof(unsigned)) {
+      // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
+      V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
+      V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
+      if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
+      grid = (unsigned)(V.n_sets * batch);
+    }
     SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + batch * 16.0));
-    hipLaunchKernelGGL((k_logits_f16x<0, kOutUB>), dim3((unsigned)(V.n_groups * batch)), dim3(512), 0, s, V);
+    if (V.n_sets > 0) hipLaunchKernelGGL((k_logits_f16x<0, kOutUB, true>), dim3(grid), dim3(512), 0, s, V);
+    else hipLaunchKernelGGL((k_logits_f16x<0, kOutUB, false>), dim3(grid), dim3(512), 0, s, V);
   }
   hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, w.stats);
   hipLaunchKernelGGL(k_sel_accumulate, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, gsum);
