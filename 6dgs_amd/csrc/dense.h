@@ -11,6 +11,7 @@ int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipSt
 size_t dense_chain_bytes_per_ray();
 // rays -> through the plane-to-plane layers -> fp32 keys kdst [m][384], or (kplanes != null; m's start a multiple of 128 rays) the scorer's
 // fp16 key planes [m][1536 B] with kinv[tile of 128 rays] = reciprocal tile scale, identical to sixdgs_split_planes_f16 of the fp32 keys
+// knorm_max (with kplanes; may be null): *knorm_max = max(*knorm_max, max over the m rays of |key row|), rounded up -- from the k_proj epilogue
 int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* kplanes,
-                float* kinv, char* ws, hipStream_t s);
+                float* kinv, float* knorm_max, char* ws, hipStream_t s);
 }  // namespace sdg

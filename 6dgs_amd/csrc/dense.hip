@@ -70,6 +70,7 @@ struct DenseArgs {
   float* out_f32;        // [M][ldo] or null (exactly one of out_planes / out_f32)
   int64_t ldo;
   int relu;
+  unsigned* out_norm_max; // or null (with out_tile_inv): *out_norm_max = max(*out_norm_max, bit pattern of max over the rays of |key row|, rounded up)
   float* out_tile_inv;   // or null.  Non-null (with out_planes, N = 384): the planes are the SCORER's key planes -- one power-of-two scale per
                          // tile of 128 rays (largest magnitude in [2^13, 2^14)), out_tile_inv[tile] = its reciprocal; out_shift is not written
 };
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   __shared__ __attribute__((aligned(16))) float cwb[2 * kMaxN];        // the layer's reciprocal weight-row scales [n] and biases [n] (loaded once per workgroup)
   __shared__ int shl[kMaxGroups][RT];                                  // input shifts of the tile's rays, per 128-input block
   __shared__ unsigned tile_max;                                        // key-plane mode: the tile's largest magnitude (bit pattern)
+  __shared__ float rsq[NTM == 3 ? 4 : 1][NTM == 3 ? RT : 1];           // key-plane mode: per feature wave, the rays' partial sums of squares
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ks = A.ks0 + A.ks1;
@@ -374,7 +376,32 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           }
         }
       }
+      if (NTM == 3 && tile_mode && A.out_norm_max != nullptr) {
+        // |key row| of the tile's rays (the select path derives its slack from the largest one, sixdgs.h): this lane's 48 features of
+        // each of its rays, + the partner lane's, one slot per feature wave -- summed in a fixed order behind the barrier (deterministic)
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn) {
+          f32x2_t q2 = {0.f, 0.f};
+#pragma unroll
+          for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2_t v = {acc[tm][tn][r], acc[tm][tn][r + 1]};
+              q2 = __builtin_elementwise_fma(v, v, q2);
+            }
+          float rs = q2.x + q2.y;
+          rs += __shfl_xor(rs, 32, 64);
+          if (lane_e < 32) rsq[NTM == 3 ? wm_e : 0][NTM == 3 ? rayl_e + 32 * tn : 0] = rs;
+        }
+      }
       __syncthreads();
+      if (NTM == 3 && tile_mode && A.out_norm_max != nullptr && te < (unsigned)RT) {
+        const int ri = NTM == 3 ? (int)te : 0;
+        float n2 = (rsq[0][ri] + rsq[NTM == 3 ? 1 : 0][ri]) + (rsq[NTM == 3 ? 2 : 0][ri] + rsq[NTM == 3 ? 3 : 0][ri]);
+        n2 = ray0 + (int64_t)te < A.m ? n2 : 0.f;
+        n2 = sdg_wave_max(n2);
+        if (lane_e == 0 && n2 > 0.f) atomicMax(A.out_norm_max, __float_as_uint(sqrtf(n2) * 1.000244140625f));
+      }
       if (planes_out) {
         // every wave splits its values now (in place: 4 values -> 2 registers of h, 2 of l): the unit loop below only moves bytes
 #pragma unroll
@@ -662,7 +689,7 @@ size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 
 
 // ori/dir/rgb of m rays -> fp32 keys kdst [m][384] (row stride 384).  ws: dense_chain_bytes_per_ray() * (m rounded up to 128) bytes, 256-B aligned.
 int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* kplanes,
-                float* kinv, char* ws, hipStream_t s) {
+                float* kinv, float* knorm_max, char* ws, hipStream_t s) {
   const size_t mp = (size_t)sdg_cdiv(m, kGran) * kGran;      // the plane buffers hold whole granules of 128 rays (tile-major layout)
   const size_t ng = mp / kGran;
   char* xp = ws;
@@ -675,19 +702,19 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
                ok = o4 + (size_t)384 * 16 * kSlabB;
   hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);
   int st;
-  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr};
+  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr, nullptr};
   if ((st = launch_dense(l1, s))) return st;
-  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr};
+  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr, nullptr};
   if ((st = launch_dense(l2, s))) return st;
-  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr};
+  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr, nullptr};
   if ((st = launch_dense(l3, s))) return st;
   // layer 4 has 384 outputs: 3 blocks; its planes reuse hp2 with 12 slabs per ray
-  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr};
+  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr, nullptr};
   if ((st = launch_dense(l4, s))) return st;
   // k_proj: fp32 keys, or (kplanes) straight the scorer's key planes -- a 128-ray tile of the 384 x 128 shape IS a key tile, so the split
   // kernel and the fp32 keys' trip through HBM drop out
   DenseArgs l5 = {wplanes + ok, w->mk, w->bk, hp2, sb, nullptr, nullptr, 12, 0, 3, 0, m, 384, kplanes, nullptr, kplanes ? nullptr : kdst, SIXDGS_D, 0,
-                  kplanes ? kinv : nullptr};
+                  kplanes ? reinterpret_cast<unsigned*>(knorm_max) : nullptr, kplanes ? kinv : nullptr};
   return launch_dense(l5, s);
 }
 

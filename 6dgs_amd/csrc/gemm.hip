@@ -435,12 +435,12 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk) {
 
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
                     float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, nullptr, nullptr, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
+  return sixdgs_ray_keys_ex(ori, dir, rgb, r, w, feat, key, nullptr, nullptr, nullptr, ws, ws_bytes, stream, nullptr, SIXDGS_MMA_DEFAULT);
 }
 
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w, float* feat,
-                       float* key, void* key_planes, float* key_inv_scale, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
-                       sixdgs_profile* prof, int mma_mode) {
+                       float* key, void* key_planes, float* key_inv_scale, float* d_key_norm_max, void* ws, size_t ws_bytes,
+                       sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode) {
   SDG_CHECK_ARG(r >= 0 && w);
   if (r == 0) return 0;
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
@@ -477,7 +477,8 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
       char* pws = reinterpret_cast<char*>(x + (size_t)chunk * SIXDGS_D);
       fused_planes = f16 && !key;      // only the planes are wanted: k_proj writes them itself (identical to the split of its fp32 keys)
       if ((st = dense_chain(ori + 3 * r0, dir + 3 * r0, rgb + 3 * r0, m, w, reinterpret_cast<const char*>(w->planes), kd,
-                            fused_planes ? (char*)key_planes + (size_t)r0 * 1536 : nullptr, fused_planes ? key_inv_scale + r0 / 128 : nullptr, pws, s)))
+                            fused_planes ? (char*)key_planes + (size_t)r0 * 1536 : nullptr, fused_planes ? key_inv_scale + r0 / 128 : nullptr,
+                            fused_planes ? d_key_norm_max : nullptr, pws, s)))
         return st;
       kdst = kd;
     } else if (f3) {
@@ -520,8 +521,11 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
       }
     }
     if (want_key && !fused_planes) {
-      if (f16) st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
-      else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
+      if (f16) {
+        st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
+        if (!st && d_key_norm_max)      // (the fused path above takes the norms from the k_proj epilogue; here: one pass over the planes)
+          st = sixdgs_key_planes_norm_max((char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, m, d_key_norm_max, stream);
+      } else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
       if (st) return st;
     }
   }

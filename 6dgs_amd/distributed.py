@@ -303,7 +303,7 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
 
 def score_select_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
                              sample_scale: torch.Tensor, ray_offset: int, r_total: int, r_sample_total: int, topk: int = 100,
-                             max_candidates: Optional[int] = None, n_tok_host=None, profile=None, group=None, stream_state=None):
+                             max_candidates: Optional[int] = None, n_tok_host=None, profile=None, group=None, key_norm: Optional[torch.Tensor] = None):
     """The select path (top-k without materialised logits, include/sixdgs.h: sixdgs_score_select) over a scene whose key planes are
     split across the ranks of `group`; this rank holds the planes of rays [ray_offset, ray_offset + r_local) and of ITS share of the
     ray sample.  Per image and batch the ranks exchange: the sample's row statistics (2 all-reduces of 1 KB), the exact per-token
@@ -322,7 +322,9 @@ def score_select_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key_planes: t
     ss = ops.SelectStream(q, n_tok, r_local, topk, cmax, n_tok_host)
     stats = merge_row_stats(ss.sample_stats(sample_planes, sample_scale), group)             # identical ctok on every rank
     ss.prepare(stats, r_sample_total, r_total)
-    ss.sweep(key_planes, key_scale, 0, profile)
+    if key_norm is not None:                    # max |k_r| of the local planes, kept beside them (otherwise: one more pass over the planes)
+        ss.key_norm.copy_(key_norm)
+    ss.sweep(key_planes, key_scale, 0, profile, update_norm=key_norm is None)
     _all_reduce(ss.gsum, dist.ReduceOp.SUM, group)                                            # exact g_t over ALL rays
     _all_reduce(ss.key_norm, dist.ReduceOp.MAX, group)
     uk = kth_largest_of_union(ss.topk_u(), min(topk, r_total), group)                         # U_(k) of the scene

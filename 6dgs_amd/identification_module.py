@@ -131,8 +131,10 @@ class IdentificationModule(torch.nn.Module):
             planes_mode = mode != ops.MMA_F32
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
             scale = None
+            norm = torch.zeros(1, device=rays_ori.device) if (planes_mode and mode in ops.F16_MODES) else None
             if planes_mode:
-                _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True)
+                # (norm: max |k_r| of the scene -- the select path's slack is derived from it, sixdgs.h: sixdgs_score_select)
+                _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True, norm_out=norm)
                 if mode in ops.F16_MODES:
                     planes, scale = planes
             else:
@@ -145,8 +147,6 @@ class IdentificationModule(torch.nn.Module):
                 si = ops.select_sample_indices(r, rays_ori.device)
                 _, _, (s_planes, s_scale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
                 sample = (s_planes, s_scale)
-            # max |k_r| of the scene: the select path's slack is derived from it (sixdgs.h: sixdgs_score_select); one pass over the planes
-            norm = ops.key_norm_max(planes, scale) if (planes_mode and mode in ops.F16_MODES) else None
             self._key_cache, self._key_cache_id = {"key": key, "planes": planes, "scale": scale, "sample": sample, "norm": norm}, ident
             self._key_cache_rays = (rays_ori, rays_dir, rays_rgb)
         return self._key_cache
@@ -327,7 +327,7 @@ class IdentificationModule(torch.nn.Module):
         self.last_scoring_path = f"ray-sharded x{world} two-pass"
         if use:
             idx, val, st = dd.score_select_ray_sharded(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], ray_offset, r_total,
-                                                       r_sample_total, k, n_tok_host=n_host, profile=profile, group=group)
+                                                       r_sample_total, k, n_tok_host=n_host, profile=profile, group=group, key_norm=kc["norm"])
             self.last_select_candidates = st
             redo = [i for i, v in enumerate(st) if v < 0]
             self.last_scoring_path = f"ray-sharded x{world} select" + (f"+two-pass({len(redo)})" if redo else "")
@@ -374,8 +374,9 @@ class IdentificationModule(torch.nn.Module):
             ss.begin(held[2], held[3])
             for r0 in range(0, r, chunk):
                 r1 = min(r0 + chunk, r)
-                _, _, (planes, scale) = ops.ray_keys(rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1], w, want_key=False, want_planes=True)
-                ss.sweep(planes, scale, r0, profile)
+                _, _, (planes, scale) = ops.ray_keys(rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1], w, want_key=False, want_planes=True,
+                                                     norm_out=ss.key_norm)
+                ss.sweep(planes, scale, r0, profile, update_norm=False)
                 del planes, scale
             cand, count = ss.candidates()
             inside = torch.arange(cmax, device=dev)[None, :] < count.clamp(min=0, max=cmax)[:, None]

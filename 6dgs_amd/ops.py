@@ -387,9 +387,11 @@ def split_planes_f16(x: torch.Tensor):
 
 @_on_device
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = 262144,
-             workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False):
+             workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False,
+             norm_out: Optional[torch.Tensor] = None):
     """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes) where planes is uint8 [R,2304]
-    (bf16 planes) or, in MMA_F16X3 mode, the pair (uint8 [R,1536] scaled fp16 planes, inv_scale [ceil(R/128)])."""
+    (bf16 planes) or, in MMA_F16X3 mode, the pair (uint8 [R,1536] scaled fp16 planes, inv_scale [ceil(R/128)]).
+    norm_out (device scalar [1], scaled fp16 planes only): updated to max(norm_out, max_r |key row|) -- see key_norm_max."""
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
     lib = _lib.load()
@@ -403,7 +405,9 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(ws), ws.numel(),
+    if norm_out is not None and not f16:
+        raise RuntimeError("6dgs_amd: norm_out needs scaled fp16 key planes (want_planes in MMA_F16X3 mode)")
+    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(norm_out), _p(ws), ws.numel(),
                                  _stream(), profile.ref if profile is not None else None, mode), "ray_keys")
     if want_planes:
         return feat, key, ((planes, inv) if f16 else planes)
@@ -616,7 +620,8 @@ class SelectStream:
         return val
 
     @_on_device
-    def sweep(self, planes, scale, ray_offset: int, profile: Optional["KernelProfile"] = None):
+    def sweep(self, planes, scale, ray_offset: int, profile: Optional["KernelProfile"] = None, update_norm: bool = True):
+        """update_norm=False: the caller already folded these planes' largest key norm into self.key_norm (ray_keys(norm_out=...))."""
         if ray_offset % 256:
             raise RuntimeError("6dgs_amd: select sweep chunks must start at a multiple of 256 rays")
         _need_gpu(self.q, planes, scale)
@@ -626,7 +631,8 @@ class SelectStream:
         check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n if profile is not None else None, self.b, _p(planes), _p(scale), rc,
                                       _p(self.ctok), _p(self.gsum), C.c_void_p(self.u.data_ptr() + 4 * int(ray_offset)), self.stride,
                                       _p(self.ws), self.ws.numel(), _stream(), profile.ref if profile is not None else None), "select_sweep")
-        key_norm_max(planes, scale, out=self.key_norm)
+        if update_norm:
+            key_norm_max(planes, scale, out=self.key_norm)
 
     @_on_device
     def candidates(self, uk: Optional[torch.Tensor] = None):

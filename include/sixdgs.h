@@ -201,9 +201,12 @@ int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_
  * the planes are kept (2304 B per ray instead of 1536 B fp32). */
 /* mma_mode == SIXDGS_MMA_F16X3: key_planes are the scaled fp16 planes (sixdgs_key_planes_f16_bytes(r) bytes, 1536 B per
  * ray) and key_inv_scale[ceil(r/128)] (device, required) receives the per-tile reciprocal scales. */
+/* d_key_norm_max (device scalar, may be NULL; scaled fp16 planes only): *d_key_norm_max = max(*d_key_norm_max, max over these rays of
+ * |key row|), rounded up -- the bound sixdgs_score_select / sixdgs_select_candidates take; zero it before the first chunk of a scene.
+ * Free when k_proj writes the planes itself (its epilogue has the rows), one pass over the planes otherwise. */
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
-                       float* feat, float* key, void* key_planes, float* key_inv_scale, void* ws, size_t ws_bytes,
-                       sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
+                       float* feat, float* key, void* key_planes, float* key_inv_scale, float* d_key_norm_max, void* ws,
+                       size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
 size_t sixdgs_key_planes_bytes(int64_t r);
 /* fp32 rows [rows][384] (row stride ld floats) -> bf16 planes [rows][12][3][32] (x = h + m + l exactly) */
 int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream);

@@ -204,6 +204,27 @@ def test_key_norm_max_bounds_every_row_norm_tightly(ops):
     assert abs(float(acc) - float(n)) <= 1e-6 * float(n)
 
 
+def test_key_norm_from_the_k_proj_epilogue_equals_the_pass_over_the_planes(ops, syn):
+    """sixdgs_ray_keys_ex(d_key_norm_max): when k_proj writes the key planes itself the norms come out of its epilogue (no extra pass
+    over 1536 B per ray -- 0.2 s per step of the streamed cfg-4 scorer otherwise); same bound as sixdgs_key_planes_norm_max of the
+    finished planes, accumulated chunk by chunk, ragged last tile included."""
+    rays = syn.make_rays(300_037, 9)
+    o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+    w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, "cuda")
+    norm = torch.zeros(1, device="cuda")
+    _, _, (planes, scale) = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, norm_out=norm, max_chunk=65536)
+    ref = ops.key_norm_max(planes, scale)
+    _, key = ops.ray_keys(o, d, c, w)
+    true = float(key.double().norm(dim=1).max())
+    assert true <= float(norm) <= true * 1.0006 and abs(float(norm) - float(ref)) <= 3e-6 * float(ref)
+    again = torch.zeros(1, device="cuda")
+    ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, norm_out=again, max_chunk=65536)
+    assert torch.equal(again, norm)                                                  # deterministic
+    both = torch.zeros(1, device="cuda")                                             # the non-fused path (fp32 keys wanted too) fills it as well
+    ops.ray_keys(o, d, c, w, want_key=True, want_planes=True, norm_out=both)
+    assert abs(float(both) - float(ref)) <= 3e-6 * float(ref)
+
+
 def test_select_slack_follows_the_logit_error_bound_single_token_large_logits(ops):
     """VERDICT r2 #9 / ADVICE r2: with ONE token g_min = g_max and the derived slack (1 - eps) / (1 + eps), eps = 1.4e-4 x + 1.3e-5,
     x = |q| max|k| / sqrt(384), is all that separates the candidates from the rest.  Logits up to ~80 (x ~ 300): the sweep's U is
