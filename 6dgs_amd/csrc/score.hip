@@ -2172,7 +2172,8 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
     // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
     unsigned grid = (unsigned)(V.n_groups * batch);
     const int cus = sibling_sync_cus();
-    if (cus > 0 && batch >= 2 && cus / batch >= 1 && w.p.topk_bytes >= (size_t)(cus / batch) * sizeof(unsigned)) {
+    // (persistent sets leave cus % batch CUs idle: only when that is at most 1/16 of the chip -- e.g. not for 100 images per launch)
+    if (cus > 0 && batch >= 2 && cus / batch >= 1 && (cus % batch) * 16 <= cus && w.p.topk_bytes >= (size_t)(cus / batch) * sizeof(unsigned)) {
       // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
       V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
       V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep

@@ -483,7 +483,9 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
 SELECT_MAX_CANDIDATES = 4096     # candidates re-scored exactly per image; an image with more falls back to the two-pass scorer
 SELECT_SAMPLE_STRIDE = 16        # the pre-pass sees one ray in 16 ...
 SELECT_SAMPLE_STRIDE_LARGE = 32  # ... one in 32 from SELECT_LARGE_RAYS rays (the sample is then still >= 0.5 M rays: its row sums are
-SELECT_LARGE_RAYS = 16_000_000   # as representative as one in 16 of a scene half the size, and the pre-pass costs half)
+SELECT_LARGE_RAYS = 16_000_000   # as representative as one in 16 of a scene half the size, and the pre-pass costs half) ...
+SELECT_SAMPLE_STRIDE_HUGE = 64   # ... one in 64 from SELECT_HUGE_RAYS rays (>= 0.5 M sample rays again).  The sample only sets the
+SELECT_HUGE_RAYS = 32_000_000    # exponent offsets and the width g_min / g_max of the bounds, never the answer
 SELECT_MIN_RAYS = 1 << 20        # below this the two-pass scorer is as fast (its logits fit in cache-sized workspaces)
 _select_enabled = True
 
@@ -500,11 +502,11 @@ def select_enabled() -> bool:
 
 @_on_device
 def select_sample_indices(r: int, device, stride: Optional[int] = None) -> torch.Tensor:
-    """One ray of every `stride` consecutive ones (default: 16, or 32 from SELECT_LARGE_RAYS rays), at a position that varies
+    """One ray of every `stride` consecutive ones (default: 16, 32 from SELECT_LARGE_RAYS rays, 64 from SELECT_HUGE_RAYS), at a position that varies
     pseudo-randomly from group to group (a fixed position would pick the same iso-cell direction of every ellipsoid):
     indices stride*i + (2654435761 i mod 2^32 >> 13) mod stride."""
     if stride is None:
-        stride = SELECT_SAMPLE_STRIDE_LARGE if r >= SELECT_LARGE_RAYS else SELECT_SAMPLE_STRIDE
+        stride = SELECT_SAMPLE_STRIDE_HUGE if r >= SELECT_HUGE_RAYS else (SELECT_SAMPLE_STRIDE_LARGE if r >= SELECT_LARGE_RAYS else SELECT_SAMPLE_STRIDE)
     n = r // stride
     i = torch.arange(n, dtype=torch.int64, device=device)
     return i * stride + (((i * 2654435761) & 0xFFFFFFFF) >> 13) % stride
