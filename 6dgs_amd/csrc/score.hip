@@ -563,7 +563,8 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   do {                                              // PERS: the ray-tile groups set, set + n_sets, ...; otherwise the one group `set`
   float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
   float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
-  float zs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 zs[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};      // [token block][r & 2]: pairs (r & 3) = (0, 1), (2, 3)
   const int t_begin = grp * t_base + min(grp, t_rem);
   const int t_end = t_begin + t_base + (grp < t_rem ? 1 : 0);
   if (PERS && !(M > 0) && A.sib_sync && t_begin < t_end) {      // an image without tokens walks no tiles: its arrivals all at once
@@ -797,19 +798,28 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
           float fin[4];
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) {
+            // two rays per instruction (round 3): the whole epilogue is VALU time the matrix pipe waits for -- 128 scalar fmas, 256 + 128
+            // scalar adds and 128 v_exp_f32 per lane and tile were 27 % of a tile; as v_pk_fma_f32 / v_pk_add_f32 on (r, r + 1) pairs the
+            // fmas and adds halve.  Same operations in the same order per value: the results are the same bits.
             float u[16];
+            const f32x2 cfl2 = {cfl, cfl}, ct0 = {ct[0], ct[0]}, ct1 = {ct[1], ct[1]};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[0][tn][r], cfl, ct[0]));
-              float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[1][tn][r], cfl, ct[1]));
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2 x0 = __builtin_elementwise_fma(f32x2{acc[0][tn][r], acc[0][tn][r + 1]}, cfl2, ct0);
+              const f32x2 x1 = __builtin_elementwise_fma(f32x2{acc[1][tn][r], acc[1][tn][r + 1]}, cfl2, ct1);
+              f32x2 e0 = {__builtin_amdgcn_exp2f(x0.x), __builtin_amdgcn_exp2f(x0.y)};
+              f32x2 e1 = {__builtin_amdgcn_exp2f(x1.x), __builtin_amdgcn_exp2f(x1.y)};
               if (ragged) {
-                const bool ok = ray0 + tn * 32 + 8 * (r >> 2) + (r & 3) <= lim_cur;   // clamped duplicates of the last ray
-                e0 = ok ? e0 : 0.f;
-                e1 = ok ? e1 : 0.f;
+                const int rr = ray0 + tn * 32 + 8 * (r >> 2) + (r & 3);                 // clamped duplicates of the last ray count as 0
+                const bool oka = rr <= lim_cur, okb = rr + 1 <= lim_cur;
+                e0 = f32x2{oka ? e0.x : 0.f, okb ? e0.y : 0.f};
+                e1 = f32x2{oka ? e1.x : 0.f, okb ? e1.y : 0.f};
               }
-              zs[0][r & 3] += e0;
-              zs[1][r & 3] += e1;
-              u[r] = e0 + e1;
+              zs[0][(r & 3) >> 1] += e0;
+              zs[1][(r & 3) >> 1] += e1;
+              const f32x2 uu = e0 + e1;
+              u[r] = uu.x;
+              u[r + 1] = uu.y;
             }
             float v8[8], v4[4], v2[2];
 #pragma unroll
@@ -933,7 +943,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     float* pp = part[wn * 2 + (lane >> 5)][wm * 64 + tm * 32 + (lane & 31)];
     if (OUT == kOutUB) {     // sums relative to the fixed reference: merged as (max 0, sum)
       pp[0] = 0.f;
-      pp[1] = (zs[tm][0] + zs[tm][1]) + (zs[tm][2] + zs[tm][3]);
+      pp[1] = (zs[tm][0].x + zs[tm][0].y) + (zs[tm][1].x + zs[tm][1].y);
     } else {
       pp[0] = m_run[tm];
       pp[1] = s_run[tm];

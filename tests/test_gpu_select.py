@@ -220,6 +220,14 @@ def test_key_norm_from_the_k_proj_epilogue_equals_the_pass_over_the_planes(ops, 
     again = torch.zeros(1, device="cuda")
     ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, norm_out=again, max_chunk=65536)
     assert torch.equal(again, norm)                                                  # deterministic
+    # and the keys themselves against the oracle at a size that spans several chunks of the chain and ends in a ragged tile (the
+    # ray MLP was oracle-checked at R <= 4096 only): 300 037 rays, every 7th compared (the OpenMP oracle takes seconds for those)
+    from oracle import oracle as O
+    O.build()
+    pick = np.arange(0, 300_037, 7)
+    _, k_ref = O.ray_features(rays["ori"][pick], rays["dir"][pick], rays["rgb"][pick], syn.make_scorer_state_dict(0))
+    k_hip = key[torch.from_numpy(pick).cuda()].cpu().numpy()
+    assert np.abs(k_hip - k_ref).max() / np.abs(k_ref).max() < 5e-6
     both = torch.zeros(1, device="cuda")                                             # the non-fused path (fp32 keys wanted too) fills it as well
     ops.ray_keys(o, d, c, w, want_key=True, want_planes=True, norm_out=both)
     assert abs(float(both) - float(ref)) <= 3e-6 * float(ref)
