@@ -239,6 +239,10 @@ def test_cfg4_2m_x256_rank_share_and_whole_scene_streamed(env, oracle):
     o_s, d_s, c_s = ori[:S], dr[:S], rgb[:S]
     i_st, v_st, glob, mass = idm.score_tokens_streamed(toks[:2], o_s, d_s, c_s, 100, chunk_rays=8_388_608, return_stats=True)
     assert np.allclose(mass.cpu().numpy(), n_t[:2], rtol=2e-4)
+    # the streamed call kept its chunks' key planes between the sweeps: eight 13 GB blocks now sit in PyTorch's caching allocator, which
+    # cannot merge them into the 98 GB of planes + 94 GB of logits the resident call needs next (seen once as an out-of-memory error with
+    # 124 GB "reserved but unallocated")
+    torch.cuda.empty_cache()
     i_rs, v_rs, sc = idm.score_tokens(toks[:2], o_s, d_s, c_s, 100, want_scores=True)
     for b in range(2):
         assert set(i_st[b].tolist()) == set(i_rs[b].tolist())                                          # same 100 rays ...
@@ -249,6 +253,7 @@ def test_cfg4_2m_x256_rank_share_and_whole_scene_streamed(env, oracle):
     key_np = host_keys(env, o_s, d_s, c_s)
     s_ref = oracle_check(oracle, env, key_np, toks[1].cpu().numpy(), s_1, i_1, v_1, "cfg-4 rank share 64M rays (streamed cut)")
     del key_np, s_ref
+    torch.cuda.empty_cache()
     # (b) the whole scene, 16 images, streamed: 2 sweeps over 64 chunks of 8 M rays
     t0 = time.time()
     idx, val, glob, mass = idm.score_tokens_streamed(toks, ori, dr, rgb, 100, chunk_rays=8_388_608, return_stats=True)
