@@ -579,7 +579,9 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     //      16-byte chunks of a row (plane * 4 + k-chunk) are XOR-swizzled with (row >> 1) & 7 on the source side, which
     //      makes the 16 lanes of every ds_read_b128 group hit 16 distinct bank groups.
     //      piece i = 0..3 of either operand: rows 8 (4 wave + i) ..
-    const int prow = lane >> 3, pos8 = lane & 7;
+    int lane_p = lane;      // (PERS: an opaque copy, so that the piece offsets below are formed per GROUP instead of being hoisted out of the
+    if (PERS) asm volatile("" : "+v"(lane_p));      // group loop and spilled across the whole kernel)
+    const int prow = lane_p >> 3, pos8 = lane_p & 7;
     unsigned offQ[4], offK[4];
     int rowK[4];
 #pragma unroll
@@ -613,8 +615,8 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
-        const int c8 = pl * 4 + 2 * ks + (lane >> 5);
-        const int ra = wm * 64 + (lane & 31), rb = wn * 128 + (lane & 31);
+        const int c8 = pl * 4 + 2 * ks + (lane_p >> 5);
+        const int ra = wm * 64 + (lane_p & 31), rb = wn * 128 + (lane_p & 31);
         fa[ks][pl] = lds0 + ra * 128 + ((c8 ^ ((ra >> 1) & 7)) << 4);
         fb[ks][pl] = lds0 + kKBaseX + rb * 128 + ((c8 ^ ((rb >> 1) & 7)) << 4);
         fb2[ks][pl] = fb[ks][pl] + 65536u;
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       return off < 65536 ? lds_read_frag_h_off(fb[ks][pl], off & 65535) : lds_read_frag_h_off(fb2[ks][pl], off & 65535);
     };
     // logits of image bl, blocked by 128-ray tiles: [tile128][token group g = t / 32][ray quad][t % 32][r % 4]
-    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + lane * 4);
+    float* lg = A.logits + (int64_t)bl * kT * A.ldl + ((wm * 2) * 4096 + lane_p * 4);
     char* lg24 = reinterpret_cast<char*>(A.logits) + (int64_t)bl * kT * A.ldl * 4;   // same per-image region, 24-bit layout
     const char* kcur = A.kp + (int64_t)t_begin * kBNX * kRowF;
     int lim_cur = tile_lim(t_begin);
