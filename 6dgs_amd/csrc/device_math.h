@@ -318,13 +318,16 @@ SDG_HD void sym_eig_3x3(const float* A, float* vals, float* vecs) {  // :246-307
 
 // ---- a4 tail: sampling.py:37-59,85-113: normal from k centred neighbours ---------------------------
 // nb: [k][3] neighbour coordinates (any order); returns the unit normal.
-SDG_HD V3 normal_from_neighbours(const float* nb, int k) {
+// `at(j)` returns neighbour j as V3 (three sweeps over the neighbours: mean, scatter matrix, sign vote)
+template <typename At>
+SDG_HD V3 normal_from_neighbours_at(At at, int k) {
   float mx = 0.f, my = 0.f, mz = 0.f;
-  for (int j = 0; j < k; ++j) { mx += nb[3 * j]; my += nb[3 * j + 1]; mz += nb[3 * j + 2]; }
+  for (int j = 0; j < k; ++j) { const V3 p = at(j); mx += p.x; my += p.y; mz += p.z; }
   mx /= (float)k; my /= (float)k; mz /= (float)k;
   float cov[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < k; ++j) {
-    float dx = nb[3 * j] - mx, dy = nb[3 * j + 1] - my, dz = nb[3 * j + 2] - mz;
+    const V3 p = at(j);
+    float dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
     cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
     cov[3] += dy * dx; cov[4] += dy * dy; cov[5] += dy * dz;
     cov[6] += dz * dx; cov[7] += dz * dy; cov[8] += dz * dz;
@@ -334,13 +337,17 @@ SDG_HD V3 normal_from_neighbours(const float* nb, int k) {
   V3 n = v3(vecs[0], vecs[3], vecs[6]);
   int npos = 0;
   for (int j = 0; j < k; ++j) {
-    float pr = (n.x * (nb[3 * j] - mx) + n.y * (nb[3 * j + 1] - my)) + n.z * (nb[3 * j + 2] - mz);
+    const V3 p = at(j);
+    float pr = (n.x * (p.x - mx) + n.y * (p.y - my)) + n.z * (p.z - mz);
     npos += (pr > 0.f) ? 1 : 0;
   }
   float sgn = ((float)npos < 0.5f * (float)k) ? -1.f : 1.f;
   n = v3(sgn * n.x, sgn * n.y, sgn * n.z);
   float d = norm(n);
   return v3(n.x / d, n.y / d, n.z / d);
+}
+SDG_HD V3 normal_from_neighbours(const float* nb, int k) {
+  return normal_from_neighbours_at([nb](int j) { return v3(nb[3 * j], nb[3 * j + 1], nb[3 * j + 2]); }, k);
 }
 
 // ---- a8: pose_estimation/isocell.py:6-84 (isrand=-1) --------------------------------------------------

@@ -52,8 +52,11 @@ __global__ void __launch_bounds__(256) k_normals_knn(const float* __restrict__ q
   bool active = qi < nq;
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (active) { qx = query[3 * qi]; qy = query[3 * qi + 1]; qz = query[3 * qi + 2]; }
-  float bd[kKnnMaxK];
-  int bi[kKnnMaxK];
+  __shared__ float s_bd[kKnnMaxK][256];      // best list [slot][thread] in LDS (as per-thread arrays with run-time indices: 400 B of scratch)
+  __shared__ int s_bi[kKnnMaxK][256];
+  const int tl = threadIdx.x;
+#define bd(J) s_bd[J][tl]
+#define bi(J) s_bi[J][tl]
   int cnt = 0;
   float worst = INFINITY;
   for (int64_t t0 = 0; t0 < E; t0 += kKnnTile) {
@@ -67,31 +70,30 @@ __global__ void __launch_bounds__(256) k_normals_knn(const float* __restrict__ q
       float d = (dx * dx + dy * dy) + dz * dz;
       if (cnt < k || d < worst) {
         int pos = cnt < k ? cnt : k - 1;
-        while (pos > 0 && bd[pos - 1] > d) {
-          bd[pos] = bd[pos - 1];
-          bi[pos] = bi[pos - 1];
+        while (pos > 0 && bd(pos - 1) > d) {
+          bd(pos) = bd(pos - 1);
+          bi(pos) = bi(pos - 1);
           --pos;
         }
-        bd[pos] = d;
-        bi[pos] = (int)(t0 + j);
+        bd(pos) = d;
+        bi(pos) = (int)(t0 + j);
         if (cnt < k) ++cnt;
-        if (cnt == k) worst = bd[k - 1];
+        if (cnt == k) worst = bd(k - 1);
       }
     }
   }
   if (!active) return;
-  float nb[kKnnMaxK * 3];
-  for (int j = 0; j < cnt; ++j) {
-    nb[3 * j] = cloud[3 * (int64_t)bi[j]];
-    nb[3 * j + 1] = cloud[3 * (int64_t)bi[j] + 1];
-    nb[3 * j + 2] = cloud[3 * (int64_t)bi[j] + 2];
-  }
-  V3 n = normal_from_neighbours(nb, cnt);
+  V3 n = normal_from_neighbours_at([&](int j) {
+    const float* c = cloud + 3 * (int64_t)bi(j);
+    return v3(c[0], c[1], c[2]);
+  }, cnt);
   normals[3 * qi] = n.x;
   normals[3 * qi + 1] = n.y;
   normals[3 * qi + 2] = n.z;
   if (knn)
-    for (int j = 0; j < k; ++j) knn[qi * k + j] = j < cnt ? bi[j] : -1;
+    for (int j = 0; j < k; ++j) knn[qi * k + j] = j < cnt ? bi(j) : -1;
+#undef bd
+#undef bi
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,8 +223,12 @@ __global__ void __launch_bounds__(128) k_normals_knn_grid(const float* __restric
   }
   const int g = p.g;
   const int cx = grid_coord(qx, p.ox, p.inv_h, g), cy = grid_coord(qy, p.oy, p.inv_h, g), cz = grid_coord(qz, p.oz, p.inv_h, g);
-  float bd[kKnnMaxK];
-  int bi[kKnnMaxK];
+  // the best list lives in LDS, [slot][thread]: as per-thread arrays with run-time indices it was 400 B of scratch per thread (round 2)
+  __shared__ float s_bd[kKnnMaxK][128];
+  __shared__ int s_bi[kKnnMaxK][128];
+  const int tl = threadIdx.x;
+#define bd(J) s_bd[J][tl]
+#define bi(J) s_bi[J][tl]
   int cnt = 0;
   float worst = INFINITY;
   int worst_i = 0x7fffffff;
@@ -235,15 +241,15 @@ __global__ void __launch_bounds__(128) k_normals_knn_grid(const float* __restric
       const int id = __float_as_int(s.w);
       if (cnt < k || d < worst || (d == worst && id < worst_i)) {
         int pos = cnt < k ? cnt : k - 1;
-        while (pos > 0 && (bd[pos - 1] > d || (bd[pos - 1] == d && bi[pos - 1] > id))) {
-          bd[pos] = bd[pos - 1];
-          bi[pos] = bi[pos - 1];
+        while (pos > 0 && (bd(pos - 1) > d || (bd(pos - 1) == d && bi(pos - 1) > id))) {
+          bd(pos) = bd(pos - 1);
+          bi(pos) = bi(pos - 1);
           --pos;
         }
-        bd[pos] = d;
-        bi[pos] = id;
+        bd(pos) = d;
+        bi(pos) = id;
         if (cnt < k) ++cnt;
-        if (cnt == k) { worst = bd[k - 1]; worst_i = bi[k - 1]; }
+        if (cnt == k) { worst = bd(k - 1); worst_i = bi(k - 1); }
       }
     }
   };
@@ -274,18 +280,18 @@ __global__ void __launch_bounds__(128) k_normals_knn_grid(const float* __restric
     }
     if (cx - s <= 0 && cx + s >= g - 1 && cy - s <= 0 && cy + s >= g - 1 && cz - s <= 0 && cz + s >= g - 1) break;
   }
-  float nb[kKnnMaxK * 3];
-  for (int j = 0; j < cnt; ++j) {
-    nb[3 * j] = cloud[3 * (int64_t)bi[j]];
-    nb[3 * j + 1] = cloud[3 * (int64_t)bi[j] + 1];
-    nb[3 * j + 2] = cloud[3 * (int64_t)bi[j] + 2];
-  }
-  const V3 n = normal_from_neighbours(nb, cnt);
+  // the neighbours' coordinates are read where they are used (three sweeps over <= 32 cached points) instead of staged in a 96-float array
+  const V3 n = normal_from_neighbours_at([&](int j) {
+    const float* c = cloud + 3 * (int64_t)bi(j);
+    return v3(c[0], c[1], c[2]);
+  }, cnt);
   normals[3 * qi] = n.x;
   normals[3 * qi + 1] = n.y;
   normals[3 * qi + 2] = n.z;
   if (knn)
-    for (int j = 0; j < k; ++j) knn[qi * k + j] = j < cnt ? bi[j] : -1;
+    for (int j = 0; j < k; ++j) knn[qi * k + j] = j < cnt ? bi(j) : -1;
+#undef bd
+#undef bi
 }
 
 // ------------------------------------------------------------------------------------------------

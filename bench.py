@@ -188,6 +188,8 @@ def main():
         counts = dd.all_counts(R, dev)
         ray_offset, R_total = sum(counts[:rank]), sum(counts)
     streamed = args.scoring == "streamed"
+    if not streamed and R * 1536 > 0.9 * torch.cuda.mem_get_info(dev)[0]:
+        raise SystemExit(f"rank {rank}: the key planes of {R} rays ({R * 1536 / 2**30:.0f} GiB) do not fit this GPU: use --scoring streamed, or --parallelism ray on more GPUs")
     kprof = ops.KernelProfile()
     t0 = time.time()
     ws, inflight, k_ms, k_fl = None, args.batch, 0.0, 0.0
