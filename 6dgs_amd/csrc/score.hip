@@ -1385,19 +1385,33 @@ __global__ void __launch_bounds__(kT) k_sel_prepare(const float* __restrict__ st
   ctok[(int64_t)bl * kT + t] = ok ? -(m * kLog2e) - (log2f(z) + log2_frac) : -INFINITY;
 }
 
-// U[bl][r] = sum of the token-quarter partials that exist (waves whose 64 tokens are all padding write nothing)
+// U[bl][r] = sum of the token-quarter partials that exist (waves whose 64 tokens are all padding write nothing); tmax (or null): the
+// largest U of every 256-ray tile = of the 4 x 64 rays one wave of this kernel handles.  The k-th largest tile maximum is a lower bound
+// of the k-th largest U (k tiles hold a ray that large) and, with the top rays scattered over 10^5 tiles, almost equal to it: the
+// candidate stage takes its threshold from the tile maxima (r / 256 values) instead of a radix select over all r values of U.
 __global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub, int64_t stride, int64_t u_stride, const int* __restrict__ n_tok, int b0,
-                                                    int64_t R, float* __restrict__ U) {
+                                                    int64_t R, float* __restrict__ U, float* __restrict__ tmax, int64_t tmax_stride) {
   const int bl = blockIdx.y;
   const int nq = (n_tok[b0 + bl] + 63) >> 6;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= R) return;
-  float4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int w = 0; w < nq; ++w) {
-    const float4 v = *reinterpret_cast<const float4*>(ub + ((int64_t)bl * 4 + w) * stride + i);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  float m = -INFINITY;
+  if (i < R) {
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < nq; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(ub + ((int64_t)bl * 4 + w) * stride + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(U + (int64_t)bl * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
+    m = a.x;
+    if (i + 1 < R) m = fmaxf(m, a.y);
+    if (i + 2 < R) m = fmaxf(m, a.z);
+    if (i + 3 < R) m = fmaxf(m, a.w);
   }
-  *reinterpret_cast<float4*>(U + (int64_t)bl * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
+  if (tmax != nullptr) {
+    m = sdg_wave_max(m);
+    const int64_t tile = (i - 4 * sdg_lane()) >> 8;      // the wave's first ray / 256
+    if (sdg_lane() == 0 && tile * 256 < R) tmax[(int64_t)bl * tmax_stride + tile] = m;
+  }
 }
 
 // gsum[bl][t] += the sweep's per-token sum (stats_g holds (0, sum) pairs from k_merge_stats)
@@ -2164,9 +2178,9 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const
 }
 
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
-                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
-  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0);
+                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
+                        void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
+  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0 && (!u_tile_max || (u_stride % 256) == 0));
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && ctok && gsum && u && ws && ((uintptr_t)key_planes % 16) == 0 &&
                 ((uintptr_t)q % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)ws % 256) == 0);
@@ -2198,7 +2212,8 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
   }
   hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch), dim3(4 * kT), 0, s, w.partial, V.n_groups, w.stats);
   hipLaunchKernelGGL(k_sel_accumulate, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, gsum);
-  hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)batch), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, 0, r, u);
+  hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)batch), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, 0, r, u,
+                     u_tile_max, u_stride / 256);
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -2214,19 +2229,22 @@ int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t
   return 0;
 }
 
-int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, int batch, int topk, float* val, void* ws, size_t ws_bytes,
-                         sixdgs_stream_t stream) {
+// the k largest values of U -- or, given the tile maxima, of THOSE: a lower bound of the k-th largest U is all the candidate stage needs
+int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, const float* u_tile_max, int batch, int topk, float* val, void* ws,
+                         size_t ws_bytes, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(u && val && ws && ((uintptr_t)ws % 256) == 0);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, topk, 8, &w, false)) return SIXDGS_E_WORKSPACE;
+  const int64_t nt = sdg_cdiv(r, 256);
+  if (u_tile_max && nt >= 2 * (int64_t)topk) return run_topk(u_tile_max, u_stride / 256, nt, batch, topk, w.idxU, val, w.topk_ws, sdg_stream(stream));
   return run_topk(u, u_stride, r, batch, topk, w.idxU, val, w.topk_ws, sdg_stream(stream));
 }
 
-int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
-                             const float* d_key_norm_max, const float* d_uk, int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws,
-                             size_t ws_bytes, sixdgs_stream_t stream) {
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* u_tile_max, const float* q, const int32_t* d_n_tok, int batch,
+                             const float* gsum, const float* d_key_norm_max, const float* d_uk, int topk, int max_candidates, int64_t* cand,
+                             int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= r && topk >= 1 && topk <= 1024 && max_candidates >= topk && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(u && q && d_n_tok && gsum && d_key_norm_max && cand && d_count && ws && ((uintptr_t)ws % 256) == 0 && ((uintptr_t)q % 16) == 0);
@@ -2237,7 +2255,11 @@ int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const 
   if (d_uk) {        // ray-sharded: U_(k) over the rays of ALL shards (the caller merged the shards' sixdgs_select_topk_u lists)
     hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, d_uk, q, d_key_norm_max, 1, 1, w.info);
   } else {
-    int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
+    // U_(k), or a lower bound of it: the k-th largest TILE maximum (k tiles hold a ray at least that large) -- r / 256 values instead of
+    // six passes over the r values of U.  A lower threshold only admits more candidates (measured: +0..3), never drops one.
+    const int64_t nt = sdg_cdiv(r, 256);
+    int st = (u_tile_max && nt >= 2 * (int64_t)topk) ? run_topk(u_tile_max, u_stride / 256, nt, batch, topk, w.idxU, w.valU, w.topk_ws, s)
+                                                      : run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);
     if (st) return st;
     hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info);
   }
@@ -2278,7 +2300,8 @@ size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int m
   // stage scratch + ctok, gsum [B,256], U [B, stride], cand [B, cmax], count [B]
   const size_t stride = (size_t)sdg_cdiv(r > 0 ? r : 1, 256) * 256;
   return sdg_align(sixdgs_select_workspace_bytes(r, batch, topk, max_candidates)) +
-         (size_t)batch * (2 * sdg_align(kT * sizeof(float)) + sdg_align(stride * sizeof(float)) + sdg_align((size_t)max_candidates * sizeof(int64_t)) + 256);
+         (size_t)batch * (2 * sdg_align(kT * sizeof(float)) + sdg_align(stride * sizeof(float)) + sdg_align(stride / 256 * sizeof(float)) +
+                          sdg_align((size_t)max_candidates * sizeof(int64_t)) + 256);
 }
 
 int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
@@ -2299,6 +2322,7 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
   float* ctok = (float*)base;                        base += (size_t)bg * sdg_align(kT * sizeof(float));
   float* gsum = (float*)base;                        base += (size_t)bg * sdg_align(kT * sizeof(float));
   float* u = (float*)base;                           base += (size_t)bg * sdg_align(stride * sizeof(float));
+  float* utm = (float*)base;                         base += (size_t)bg * sdg_align(stride / 256 * sizeof(float));
   int64_t* cand = (int64_t*)base;                    base += (size_t)bg * sdg_align((size_t)max_candidates * sizeof(int64_t));
   int32_t* count = (int32_t*)base;
   for (int b0 = 0; b0 < batch; b0 += (int)bg) {
@@ -2307,10 +2331,10 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
     const int32_t* ng = d_n_tok + b0;
     int st = sixdgs_select_begin(qg, ng, nb, sample_planes, d_sample_scale, r_sample, r, ctok, gsum, ws, stage, stream);
     if (st) return st;
-    st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, ws, stage,
+    st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, utm, ws, stage,
                              stream, prof);
     if (st) return st;
-    st = sixdgs_select_candidates(u, (int64_t)stride, r, qg, ng, nb, gsum, d_key_norm_max, nullptr, topk, max_candidates, cand, count, ws, stage, stream);
+    st = sixdgs_select_candidates(u, (int64_t)stride, r, utm, qg, ng, nb, gsum, d_key_norm_max, nullptr, topk, max_candidates, cand, count, ws, stage, stream);
     if (st) return st;
     st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates, 0,
                                idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, stream);

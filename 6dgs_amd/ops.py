@@ -574,6 +574,7 @@ class SelectStream:
         self.ctok = torch.empty(self.b, MAX_TOKENS, device=self.dev)
         self.gsum = torch.empty(self.b, MAX_TOKENS, device=self.dev)
         self.u = torch.empty(self.b, self.stride, device=self.dev)
+        self.utm = torch.empty(self.b, self.stride // 256, device=self.dev)        # the largest U of every 256-ray tile (candidate threshold)
         self.key_norm = torch.zeros(1, device=self.dev)        # max |k_r| over the chunks swept so far (the bound of the candidate stage)
         self.ws = torch.empty(1, dtype=torch.uint8, device=self.dev)
         self.h_n = (C.c_int32 * self.b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
@@ -612,12 +613,13 @@ class SelectStream:
 
     @_on_device
     def topk_u(self) -> torch.Tensor:
-        """The k largest U of the rays swept so far, per image, descending (NaN-padded when there are fewer than k rays)."""
+        """The k largest TILE MAXIMA of U over the rays swept so far, per image, descending (the k largest U themselves for scenes of fewer than
+        2 k tiles): the k-th of them is a lower bound of the k-th largest U, which is what the candidate threshold needs."""
         lib = _lib.load()
         _need_gpu(self.q)
         self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
         val = torch.empty(self.b, self.topk, device=self.dev)
-        check(lib.sixdgs_select_topk_u(_p(self.u), self.stride, self.r, self.b, self.topk, _p(val), _p(self.ws), self.ws.numel(), _stream()),
+        check(lib.sixdgs_select_topk_u(_p(self.u), self.stride, self.r, _p(self.utm), self.b, self.topk, _p(val), _p(self.ws), self.ws.numel(), _stream()),
               "select_topk_u")
         return val
 
@@ -632,6 +634,7 @@ class SelectStream:
         self._grow(lib.sixdgs_select_workspace_bytes(rc, self.b, self.topk, self.cmax))
         check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n if profile is not None else None, self.b, _p(planes), _p(scale), rc,
                                       _p(self.ctok), _p(self.gsum), C.c_void_p(self.u.data_ptr() + 4 * int(ray_offset)), self.stride,
+                                      C.c_void_p(self.utm.data_ptr() + 4 * (int(ray_offset) // 256)),
                                       _p(self.ws), self.ws.numel(), _stream(), profile.ref if profile is not None else None), "select_sweep")
         if update_norm:
             key_norm_max(planes, scale, out=self.key_norm)
@@ -646,7 +649,7 @@ class SelectStream:
         cand = torch.zeros(self.b, self.cmax, dtype=torch.int64, device=self.dev)
         count = torch.empty(self.b, dtype=torch.int32, device=self.dev)
         uk = _f32(uk) if uk is not None else None
-        check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.q), _p(self.n_tok), self.b, _p(self.gsum), _p(self.key_norm),
+        check(lib.sixdgs_select_candidates(_p(self.u), self.stride, self.r, _p(self.utm), _p(self.q), _p(self.n_tok), self.b, _p(self.gsum), _p(self.key_norm),
                                            _p(uk), self.topk, self.cmax, _p(cand), _p(count), _p(self.ws), self.ws.numel(), _stream()), "select_candidates")
         return cand, count
 

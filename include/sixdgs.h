@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -317,12 +317,16 @@ int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, int batch
                                int64_t r_sample, float* row_stats /*[B,256,2]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_select_prepare(const float* row_stats, const int32_t* d_n_tok, int batch, int64_t r_sample, int64_t r_total, float* ctok, float* gsum,
                           sixdgs_stream_t stream);
-int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, int batch, int topk, float* val /*[B,topk]*/, void* ws, size_t ws_bytes,
-                         sixdgs_stream_t stream);        /* ws: sixdgs_select_candidates_workspace_bytes */
+int sixdgs_select_topk_u(const float* u, int64_t u_stride, int64_t r, const float* u_tile_max /*or NULL*/, int batch, int topk, float* val /*[B,topk]*/,
+                         void* ws, size_t ws_bytes, sixdgs_stream_t stream);        /* ws: sixdgs_select_candidates_workspace_bytes */
+/* u_tile_max (optional, [B][u_stride / 256] floats, u_stride a multiple of 256; a chunk passes u + ray_offset and u_tile_max + ray_offset / 256):
+ * the largest U of every 256-ray tile.  The k-th largest tile maximum is a lower bound of the k-th largest U -- k tiles hold a ray that large --
+ * and with the top rays scattered over r / 256 tiles practically equal to it; `candidates` (and `topk_u`) take it from these r / 256 values
+ * instead of a radix select over all r values of U (six passes less over U per batch).  A lower threshold admits a few more candidates, never fewer. */
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, void* ws,
-                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
-int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
+                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
+                        void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof);
+int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const float* u_tile_max /*or NULL*/, const float* q, const int32_t* d_n_tok, int batch, const float* gsum,
                              const float* d_key_norm_max, const float* d_uk /*[B] k-th largest U of the whole scene, or NULL = of these rays*/,
                              int topk, int max_candidates, int64_t* cand, int32_t* d_count, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_select_rescore(const float* q, const int32_t* d_n_tok, int batch, const void* planes, const float* d_scale, int compact,
