@@ -1237,10 +1237,11 @@ __device__ SelectState select_state(const unsigned* hist /*[4][256] of this imag
 
 template <int PASS>
 __global__ void __launch_bounds__(256) k_topk_hist(const float* __restrict__ scores, int64_t stride, int64_t R, unsigned k,
-                                                    unsigned* __restrict__ hist_all) {
+                                                    unsigned* __restrict__ hist_all, const int* __restrict__ only) {
   __shared__ unsigned sm[256];
   __shared__ unsigned lh[256];
   const int b = blockIdx.y;
+  if (only != nullptr && only[b] == 0) return;      // (an image this selection is not needed for: the whole block leaves)
   unsigned* hist = hist_all + (int64_t)b * 4 * 256;
   const SelectState st = select_state(hist, PASS, k, sm);
   for (int i = threadIdx.x; i < 256; i += blockDim.x) lh[i] = 0;
@@ -1265,10 +1266,12 @@ __global__ void __launch_bounds__(256) k_topk_gather(const float* __restrict__ s
                                                       const unsigned* __restrict__ hist_all, int64_t span,
                                                       unsigned* __restrict__ counts /*[B][NB][2]*/,
                                                       const unsigned* __restrict__ offs /*[B][NB][2] exclusive*/,
-                                                      unsigned* __restrict__ cand_key, int64_t* __restrict__ cand_idx, int topk) {
+                                                      unsigned* __restrict__ cand_key, int64_t* __restrict__ cand_idx, int topk,
+                                                      const int* __restrict__ only) {
   __shared__ unsigned sm[256];
   __shared__ int sc[2][5];
   const int b = blockIdx.y;
+  if (only != nullptr && only[b] == 0) return;
   const SelectState st = select_state(hist_all + (int64_t)b * 4 * 256, 4, k, sm);
   const unsigned thr = st.prefix;
   const float* s = scores + (int64_t)b * stride;
@@ -1322,9 +1325,10 @@ __global__ void __launch_bounds__(256) k_topk_gather(const float* __restrict__ s
   }
 }
 
-__global__ void __launch_bounds__(1024) k_topk_scan(const unsigned* __restrict__ counts, int nb, unsigned* __restrict__ offs) {
+__global__ void __launch_bounds__(1024) k_topk_scan(const unsigned* __restrict__ counts, int nb, unsigned* __restrict__ offs, const int* __restrict__ only) {
   __shared__ unsigned sm[17];
   const int b = blockIdx.x;
+  if (only != nullptr && only[b] == 0) return;
   for (int comp = 0; comp < 2; ++comp) {
     unsigned base = 0;
     for (int c0 = 0; c0 < nb; c0 += 1024) {
@@ -1340,10 +1344,11 @@ __global__ void __launch_bounds__(1024) k_topk_scan(const unsigned* __restrict__
 
 // sort the <= 1024 candidates by (key desc, index asc) and emit idx/val; pads with (-1, NaN)
 __global__ void __launch_bounds__(1024) k_topk_sort(const unsigned* __restrict__ cand_key, const int64_t* __restrict__ cand_idx,
-                                                     int topk, int k_eff, int64_t* __restrict__ idx, float* __restrict__ val) {
+                                                     int topk, int k_eff, int64_t* __restrict__ idx, float* __restrict__ val, const int* __restrict__ only) {
   __shared__ unsigned sk[1024];
   __shared__ long long si[1024];
   const int b = blockIdx.x, t = threadIdx.x;
+  if (only != nullptr && only[b] == 0) return;
   if (t < k_eff) { sk[t] = cand_key[(int64_t)b * topk + t]; si[t] = cand_idx[(int64_t)b * topk + t]; }
   else { sk[t] = 0u; si[t] = 0x7fffffffffffffffll; }
   __syncthreads();
@@ -1463,9 +1468,10 @@ __global__ void __launch_bounds__(256) k_plane_norm_max(const char* __restrict__
 constexpr float kEpsPerX = 1.4e-4f, kEpsConst = 1.3e-5f;
 __global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ gsum, const int* __restrict__ n_tok, const float* __restrict__ valU,
                                                    const float* __restrict__ q, const float* __restrict__ key_norm_max, int topk, int k_eff,
-                                                   float* __restrict__ info) {
+                                                   float* __restrict__ info, const int* __restrict__ only) {
   __shared__ float smin[4], smax[4], sq[4];
   const int bl = blockIdx.x, t = threadIdx.x, M = n_tok[bl];
+  if (only != nullptr && only[bl] == 0) return;
   const float g = gsum[(int64_t)bl * kT + t];
   float lo = t < M ? g : INFINITY, hi = t < M ? g : -INFINITY;
   bool bad = t < M && !(g > 0.f && g < INFINITY);
@@ -1508,6 +1514,14 @@ __global__ void __launch_bounds__(kT) k_sel_bounds(const float* __restrict__ gsu
   }
 }
 
+// need[bl] = 1 when the threshold taken from the TILE maxima admitted more than cmax candidates (the top rays sit in few tiles, the k-th
+// largest tile maximum is then far below the k-th largest U): that image gets the exact k-th largest U after all
+__global__ void k_sel_need_exact(const int* __restrict__ total, const float* __restrict__ info, int nb, int cmax, int* __restrict__ need) {
+  const int bl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bl >= nb) return;
+  need[bl] = (info[bl * 4 + 1] == 0.f && total[bl] > cmax) ? 1 : 0;
+}
+
 // d_count[bl] = number of candidates (may exceed max_candidates: the re-score stage then refuses), -1 bounds unusable, -2 no tokens
 __global__ void k_sel_count(const int* __restrict__ total, const float* __restrict__ info, int nb, int* __restrict__ d_count) {
   const int bl = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1520,9 +1534,10 @@ __global__ void k_sel_count(const int* __restrict__ total, const float* __restri
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_sel_candidates(const float* __restrict__ U, int64_t stride, int64_t R, const float* __restrict__ info,
                                                         int64_t span, unsigned* __restrict__ counts, const unsigned* __restrict__ offs,
-                                                        int64_t* __restrict__ cand, int cmax) {
+                                                        int64_t* __restrict__ cand, int cmax, const int* __restrict__ only) {
   __shared__ int sc[4];
   const int bl = blockIdx.y;
+  if (only != nullptr && only[bl] == 0) return;
   const float thr = info[bl * 4 + 0];
   const float* u = U + (int64_t)bl * stride;
   const int64_t i0 = (int64_t)blockIdx.x * span, i1 = min(i0 + span, R);
@@ -1683,8 +1698,9 @@ TopkPlan topk_plan(int64_t r, int batch, int topk) {
   return p;
 }
 
+// only (device, [batch], or null = all): images with only[b] == 0 are skipped -- their idx / val rows keep what they held
 int run_topk(const float* scores, int64_t stride, int64_t r, int batch, int topk, int64_t* idx, float* val, char* ws,
-             hipStream_t s) {
+             hipStream_t s, const int* only = nullptr) {
   const TopkPlan p = topk_plan(r, batch, topk);
   unsigned* hist = (unsigned*)(ws + p.off_hist);
   unsigned* counts = (unsigned*)(ws + p.off_counts);
@@ -1698,18 +1714,18 @@ int run_topk(const float* scores, int64_t stride, int64_t r, int batch, int topk
     int64_t hb = sdg_cdiv(r, 256 * 8);
     if (hb > 1024) hb = 1024;
     const dim3 hg((unsigned)hb, (unsigned)batch);
-    hipLaunchKernelGGL(k_topk_hist<0>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
-    hipLaunchKernelGGL(k_topk_hist<1>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
-    hipLaunchKernelGGL(k_topk_hist<2>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
-    hipLaunchKernelGGL(k_topk_hist<3>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist);
+    hipLaunchKernelGGL(k_topk_hist<0>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, only);
+    hipLaunchKernelGGL(k_topk_hist<1>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, only);
+    hipLaunchKernelGGL(k_topk_hist<2>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, only);
+    hipLaunchKernelGGL(k_topk_hist<3>, hg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, only);
     const dim3 gg((unsigned)p.nb, (unsigned)batch);
     hipLaunchKernelGGL(k_topk_gather<false>, gg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, p.span, counts, offs,
-                       ckey, cidx, topk);
-    hipLaunchKernelGGL(k_topk_scan, dim3((unsigned)batch), dim3(1024), 0, s, counts, p.nb, offs);
+                       ckey, cidx, topk, only);
+    hipLaunchKernelGGL(k_topk_scan, dim3((unsigned)batch), dim3(1024), 0, s, counts, p.nb, offs, only);
     hipLaunchKernelGGL(k_topk_gather<true>, gg, dim3(256), 0, s, scores, stride, r, (unsigned)k_eff, hist, p.span, counts, offs,
-                       ckey, cidx, topk);
+                       ckey, cidx, topk, only);
   }
-  hipLaunchKernelGGL(k_topk_sort, dim3((unsigned)batch), dim3(1024), 0, s, ckey, cidx, topk, k_eff, idx, val);
+  hipLaunchKernelGGL(k_topk_sort, dim3((unsigned)batch), dim3(1024), 0, s, ckey, cidx, topk, k_eff, idx, val, only);
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -2252,21 +2268,41 @@ int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const 
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, topk, max_candidates, &w, false)) return SIXDGS_E_WORKSPACE;
   const int k_eff = (int)(r < topk ? r : topk);
-  if (d_uk) {        // ray-sharded: U_(k) over the rays of ALL shards (the caller merged the shards' sixdgs_select_topk_u lists)
-    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, d_uk, q, d_key_norm_max, 1, 1, w.info);
-  } else {
-    // U_(k), or a lower bound of it: the k-th largest TILE maximum (k tiles hold a ray at least that large) -- r / 256 values instead of
-    // six passes over the r values of U.  A lower threshold only admits more candidates (measured: +0..3), never drops one.
-    const int64_t nt = sdg_cdiv(r, 256);
-    int st = (u_tile_max && nt >= 2 * (int64_t)topk) ? run_topk(u_tile_max, u_stride / 256, nt, batch, topk, w.idxU, w.valU, w.topk_ws, s)
-                                                      : run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);
-    if (st) return st;
-    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info);
-  }
   const dim3 cg((unsigned)w.p.nbc, (unsigned)batch);
-  hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
-  hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
-  hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates);
+  const int64_t nt = sdg_cdiv(r, 256);
+  const bool tiles = !d_uk && u_tile_max && nt >= 2 * (int64_t)topk;
+  const int* none = nullptr;
+  if (d_uk) {        // ray-sharded: U_(k) -- or a lower bound of it -- over the rays of ALL shards (the caller merged the shards' sixdgs_select_topk_u lists)
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, d_uk, q, d_key_norm_max, 1, 1, w.info, none);
+  } else if (!tiles) {
+    int st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s);      // U_(k): the k-th largest upper bound
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info, none);
+  } else {
+    // A lower bound of U_(k) is enough for a threshold, and the k-th largest TILE maximum is one (k tiles hold a ray at least that large):
+    // a top-k over r / 256 values instead of six passes over the r values of U.  With the top rays scattered over the scene it is
+    // practically U_(k) (headline: 113-120 candidates against 107-112).  When they are not -- all of the top rays in a handful of tiles --
+    // the bound is far too low; that shows as more than max_candidates candidates, and exactly those images get the exact U_(k): every
+    // kernel of the second selection leaves at once for the other images (`need`), so the common case pays only empty launches.
+    int* need = w.total + batch;
+    int st = run_topk(u_tile_max, u_stride / 256, nt, batch, topk, w.idxU, w.valU, w.topk_ws, s);
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, topk, w.info, none);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
+    hipLaunchKernelGGL(k_sel_need_exact, dim3((unsigned)sdg_cdiv(batch, 64)), dim3(64), 0, s, w.total, w.info, batch, max_candidates, need);
+    st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s, need);
+    if (st) return st;
+    hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info, need);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, need);
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
+    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+  }
+  if (!tiles) {
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
+    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+  }
   hipLaunchKernelGGL(k_sel_count, dim3((unsigned)sdg_cdiv(batch, 64)), dim3(64), 0, s, w.total, w.info, batch, d_count);
   SDG_LAUNCH_OK();
   return 0;
