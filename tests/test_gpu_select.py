@@ -93,7 +93,10 @@ def test_select_matches_two_pass_and_oracle(ops, oracle, q_scale, name):
 
 
 def test_select_zero_token_image_and_tile_scales(ops, oracle):
-    c = make_case(ops, 1_100_000, 5, 1.0, (256, 0, 64), key_spread=0.7)      # 128-ray tiles whose magnitudes differ by up to ~20x
+    # 128-ray tiles whose magnitudes differ by up to ~20x.  All of the top rays then sit in a handful of tiles: the k-th largest TILE maximum of U
+    # (the round-3 threshold) is far below the k-th largest U, more than max_candidates rays pass it, and the image must be caught by the per-image
+    # exact selection inside sixdgs_select_candidates -- not refused (this very case was, until that fallback existed)
+    c = make_case(ops, 1_100_000, 5, 1.0, (256, 0, 64), key_spread=0.7)
     st = check_against_two_pass_and_oracle(ops, oracle, c, oracle_images=(0, 2))
     assert st[1] == 0                                                              # the image without tokens: all scores are exactly 0
     # tiles 10^4 apart: the logits of the largest tiles run into the hundreds and the sample maximum is exceeded by more than
