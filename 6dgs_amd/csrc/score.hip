@@ -1534,16 +1534,19 @@ __global__ void k_sel_count(const int* __restrict__ total, const float* __restri
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_sel_candidates(const float* __restrict__ U, int64_t stride, int64_t R, const float* __restrict__ info,
                                                         int64_t span, unsigned* __restrict__ counts, const unsigned* __restrict__ offs,
-                                                        int64_t* __restrict__ cand, int cmax, const int* __restrict__ only) {
+                                                        int64_t* __restrict__ cand, int cmax, const int* __restrict__ only,
+                                                        const float* __restrict__ tmax_all) {
   __shared__ int sc[4];
   const int bl = blockIdx.y;
   if (only != nullptr && only[bl] == 0) return;
   const float thr = info[bl * 4 + 0];
   const float* u = U + (int64_t)bl * stride;
+  const float* tmax = tmax_all ? tmax_all + (int64_t)bl * (stride >> 8) : nullptr;
   const int64_t i0 = (int64_t)blockIdx.x * span, i1 = min(i0 + span, R);
   unsigned run = 0;
   const unsigned base = WRITE ? offs[(int64_t)bl * gridDim.x + blockIdx.x] : 0u;
   for (int64_t c0 = i0; c0 < i1; c0 += 256) {
+    if (tmax != nullptr && !(tmax[c0 >> 8] >= thr)) continue;      // no ray of this 256-ray tile reaches the threshold: 4 B read instead of 1 KB
     const int64_t i = c0 + threadIdx.x;
     const bool in = i < i1 && u[i] >= thr;
     const unsigned long long bm = __ballot(in);
@@ -2288,20 +2291,20 @@ int sixdgs_select_candidates(const float* u, int64_t u_stride, int64_t r, const 
     int st = run_topk(u_tile_max, u_stride / 256, nt, batch, topk, w.idxU, w.valU, w.topk_ws, s);
     if (st) return st;
     hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, topk, w.info, none);
-    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none, u_tile_max);
     hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
     hipLaunchKernelGGL(k_sel_need_exact, dim3((unsigned)sdg_cdiv(batch, 64)), dim3(64), 0, s, w.total, w.info, batch, max_candidates, need);
     st = run_topk(u, u_stride, r, batch, topk, w.idxU, w.valU, w.topk_ws, s, need);
     if (st) return st;
     hipLaunchKernelGGL(k_sel_bounds, dim3((unsigned)batch), dim3(kT), 0, s, gsum, d_n_tok, w.valU, q, d_key_norm_max, topk, k_eff, w.info, need);
-    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, need);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, need, u_tile_max);
     hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
-    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none, u_tile_max);
   }
   if (!tiles) {
-    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_candidates<false>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none, u_tile_max);
     hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)batch), dim3(1024), 0, s, w.counts, w.p.nbc, w.offs, w.total);
-    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none);
+    hipLaunchKernelGGL(k_sel_candidates<true>, cg, dim3(256), 0, s, u, u_stride, r, w.info, w.p.span, w.counts, w.offs, cand, max_candidates, none, u_tile_max);
   }
   hipLaunchKernelGGL(k_sel_count, dim3((unsigned)sdg_cdiv(batch, 64)), dim3(64), 0, s, w.total, w.info, batch, d_count);
   SDG_LAUNCH_OK();
