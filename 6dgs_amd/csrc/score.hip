@@ -473,6 +473,7 @@ struct LogitsF16Args {
   // score the nb images of a launch against the same ray-tile groups s, s + n_sets, ...; after every tile they meet at sib_sync[s]
   int n_sets;
   unsigned* sib_sync;    // [n_sets] zeroed before the launch
+  int sib_period;        // tiles between two meetings of a sibling set (>= 1)
 };
 // what the kernel leaves behind for each tile
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
@@ -517,15 +518,22 @@ __device__ unsigned long long g_dbg_cycles[8][8];   // [wave][phase] summed over
 //   are issued in step 3, after the slab barrier.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBNX = 256;                // rays per tile
-// How the select sweep's grid is laid out when a launch scores several images (SIXDGS_SIBLING_SYNC overrides):
-//   0  one-shot grid, one workgroup per (ray-tile group, image) -- round 2.  Workgroups start whenever a CU frees up, the nb siblings of
-//      a group drift apart and re-read key tiles that already left the XCD's 4 MB L2: 1.40x the algorithmic bytes (57.77 ms per launch);
-//   2  PERSISTENT sibling sets (default): n_sets = CUs / nb sets of nb workgroups, all resident from the start, set s walks the groups
-//      s, s + n_sets, ... -- the siblings start every group together: 1.10x (58.16 ms, +0.7 %: static instead of dynamic balancing);
-//   1  the same plus a lock-step after every tile (an atomic arrival + a scalar-load spin per sibling set): 1.05x (58.69 ms, +1.6 %).
-// Measured on the headline workload, `tools/sib_ab.sh`, profiles/r03_pmc_sibling_sets.md.  The re-reads never cost time (the kernel is
-// matrix-pipe / power bound at 1.2 TB/s); the default takes the traffic down where it is free.
-constexpr int kSiblingSyncDefault = 2;
+// How the select sweep's grid is laid out when a launch scores several images (SIXDGS_SIBLING_SYNC overrides).  The nb workgroups that
+// score the nb images against the same ray-tile group ("siblings", one XCD) share the key tiles through that XCD's 4 MB L2 only while
+// they stay within about a third of a tile of each other (32 workgroups x 384 KB per tile go through the L2 at once).
+//   0  one-shot grid, one workgroup per (ray-tile group, image) -- round 2.  A sibling starts whenever a CU frees up;
+//   2  persistent sibling sets: n_sets = CUs / nb sets of nb workgroups, all resident from the start, set s walks the groups
+//      s, s + n_sets, ... -- the siblings start together ONCE and then drift at their CUs' pace;
+//   1  (default) persistent sets that meet after every tile (an atomic arrival + a spin on a scalar load per sibling set).
+// HBM bytes per launch / algorithmic bytes (FETCH_SIZE x 2 + WRITE_SIZE, headline workload), two boxes, `tools/sib_ab.sh` / `sib_ab2.sh`:
+//   mode 0: 1.40x / 1.19x      mode 2: 1.10x / 1.32x (1.15x and 1.47x in two profile runs)      mode 1: 1.05x / 1.14x      (meeting every 4th / 8th tile: 1.24x / 1.25x)
+// -- only the per-tile meeting is better on every box.  Launch time by HIP events: 57.77 / 58.16 / 58.69 ms on the first box, 59.9 / 60.3 / 60.1 ms on the
+// second (under the PMC pass): the meeting costs 0.2-1.6 % (a tile takes as long as its slowest sibling), less than the boxes differ (56.5-61 ms).  The
+// re-reads themselves never cost time -- the kernel is matrix-pipe / power bound at 1.0-1.3 TB/s -- the default takes the bytes down where that is nearly free.
+// No deadlock: a set's resident members spin only until the set's other members are dispatched, which needs a free CU, which the sets whose members
+// are all resident provide by finishing (workgroups are dispatched in blockIdx order: the resident prefix consists of whole sets but one).
+constexpr int kSiblingSyncDefault = 1;
+constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1; SIXDGS_SIB_PERIOD overrides)
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
 // for that token in this tile).  0.766 x the bytes of fp32 logits, written once and read once per image.
@@ -568,8 +576,9 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   const int t_begin = grp * t_base + min(grp, t_rem);
   const int t_end = t_begin + t_base + (grp < t_rem ? 1 : 0);
   if (PERS && !(M > 0) && A.sib_sync && t_begin < t_end) {      // an image without tokens walks no tiles: its arrivals all at once
-    if (tid == 0) atomicAdd(A.sib_sync + set, (unsigned)(t_end - t_begin));
-    sib_target += (unsigned)(A.nb * (t_end - t_begin));
+    const unsigned meets = (unsigned)((t_end - t_begin + A.sib_period - 1) / A.sib_period);
+    if (tid == 0) atomicAdd(A.sib_sync + set, meets);
+    sib_target += (unsigned)A.nb * meets;
   }
   if (M > 0 && t_begin < t_end) {
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
@@ -747,11 +756,11 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       }
 
       // ---- sibling lock-step: the nb workgroups of this sibling set (same XCD: consecutive work items of the remap) meet here after
-      // every tile, so that they stay within a tile of each other and the key slabs one of them pulls from HBM are still in the XCD's
+      // every sib_period-th tile (and after a group's last one), so that they stay within a fraction of a tile of each other and the key slabs one of them pulls from HBM are still in the XCD's
       // L2 when the others ask for them (round 2 measured 1.40x the algorithmic bytes: the siblings started together and drifted).
       // Wave 0 announces (one atomic without return) and spins on a SCALAR load (lgkmcnt: the ring's vmcnt bookkeeping is untouched); the
       // other waves run on into the epilogue and the next tile's first slab, where the slab barrier holds them for wave 0.
-      if (PERS && A.sib_sync != nullptr) {
+      if (PERS && A.sib_sync != nullptr && (((tile - t_begin) % A.sib_period) == A.sib_period - 1 || tile + 1 == t_end)) {
         sib_target += (unsigned)A.nb;
         if (wave == 0) {
           unsigned* const sp = A.sib_sync + set;
@@ -2222,6 +2231,10 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
       // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
       V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
       V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
+      {
+        static const int period = [] { const char* e = getenv("SIXDGS_SIB_PERIOD"); const int v = e ? atoi(e) : kSibPeriod; return v >= 1 ? v : 1; }();
+        V.sib_period = period;
+      }
       if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
       grid = (unsigned)(V.n_sets * batch);
     }
