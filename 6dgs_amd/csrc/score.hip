@@ -531,7 +531,7 @@ constexpr int kBNX = 256;                // rays per tile
 // second (under the PMC pass): the meeting costs 0.2-1.6 % (a tile takes as long as its slowest sibling), less than the boxes differ (56.5-61 ms).  The
 // re-reads themselves never cost time -- the kernel is matrix-pipe / power bound at 1.0-1.3 TB/s -- the default takes the bytes down where that is nearly free.
 // No deadlock: a set's resident members spin only until the set's other members are dispatched, which needs a free CU, which the sets whose members
-// are all resident provide by finishing (workgroups are dispatched in blockIdx order: the resident prefix consists of whole sets but one).
+// are all resident provide by finishing (workgroups are dispatched in blockIdx order: the resident prefix consists of whole sets but one per XCD).
 constexpr int kSiblingSyncDefault = 1;
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1; SIXDGS_SIB_PERIOD overrides)
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
