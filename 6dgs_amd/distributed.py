@@ -327,7 +327,10 @@ def score_select_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key_planes: t
     ss.sweep(key_planes, key_scale, 0, profile, update_norm=key_norm is None)
     _all_reduce(ss.gsum, dist.ReduceOp.SUM, group)                                            # exact g_t over ALL rays
     _all_reduce(ss.key_norm, dist.ReduceOp.MAX, group)
-    uk = kth_largest_of_union(ss.topk_u(), min(topk, r_total), group)                         # U_(k) of the scene
+    # U_(k) of the scene from the ranks' exact k largest U.  (The single-GPU path takes a lower bound from the tile maxima of U and repairs the
+    # rare image whose top rays sit in a few tiles on the device; here that repair would be a second round of collectives, and six passes over
+    # the local U are 1 % of a rank's sweep.)
+    uk = kth_largest_of_union(ss.topk_u(exact=True), min(topk, r_total), group)
     cand, count = ss.candidates(uk=uk)
     idx, val, status = ss.rescore(key_planes, key_scale, cand, count, compact=False, allow_fewer=True)
     st = status.to(torch.int64)

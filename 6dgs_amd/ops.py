@@ -612,14 +612,17 @@ class SelectStream:
                                                 _stream()), "select_prepare")
 
     @_on_device
-    def topk_u(self) -> torch.Tensor:
+    def topk_u(self, exact: bool = False) -> torch.Tensor:
         """The k largest TILE MAXIMA of U over the rays swept so far, per image, descending (the k largest U themselves for scenes of fewer than
-        2 k tiles): the k-th of them is a lower bound of the k-th largest U, which is what the candidate threshold needs."""
+        2 k tiles): the k-th of them is a lower bound of the k-th largest U, which is what the candidate threshold needs.  exact=True: the
+        k largest U themselves (six passes over U instead of one over the tile maxima) -- the bound that does not degrade when the top
+        rays sit in a few tiles."""
         lib = _lib.load()
         _need_gpu(self.q)
         self._grow(lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax))
         val = torch.empty(self.b, self.topk, device=self.dev)
-        check(lib.sixdgs_select_topk_u(_p(self.u), self.stride, self.r, _p(self.utm), self.b, self.topk, _p(val), _p(self.ws), self.ws.numel(), _stream()),
+        check(lib.sixdgs_select_topk_u(_p(self.u), self.stride, self.r, None if exact else _p(self.utm), self.b, self.topk, _p(val), _p(self.ws),
+                                       self.ws.numel(), _stream()),
               "select_topk_u")
         return val
 
