@@ -73,10 +73,11 @@ def parse():
     ap.add_argument("--scoring", choices=["resident", "streamed"], default=None,
                     help="resident: key planes cached in HBM (1536 B/ray); streamed: ray chunks whose keys are computed, used and dropped")
     ap.add_argument("--chunk-rays", type=int, default=8_388_608, help="streamed scorer: rays per chunk")
-    ap.add_argument("--parallelism", choices=["image", "ray"], default="image",
+    ap.add_argument("--parallelism", choices=["auto", "image", "ray"], default="auto",
                     help="image: query images shard over the ranks, every rank holds the whole scene (north_star; default).  ray: the RAYS shard "
                          "over the ranks, every rank keeps the key planes of its slice resident and all ranks score the same --batch images per "
-                         "step -- for scenes whose key planes fit only across GPUs (cfg4 at N >= 4: 786 GB / N per GPU, no per-step ray MLP)")
+                         "step -- for scenes whose key planes fit only across GPUs (cfg4 at N >= 4: 786 GB / N per GPU, no per-step ray MLP).  "
+                         "auto: image, except for a streamed preset whose key planes fit the ranks' HBM together (then ray: measured 1.85x on one rank's share)")
     ap.add_argument("--mode", choices=["full", "reference"], default="full",
                     help="full: every Gaussian, iso-cell emitter (headline); reference: 1000-ellipsoid quadricell subsample")
     ap.add_argument("--mma", choices=["default", "bf16x6", "f16x3", "f16x3l32", "f32"], default="default",
@@ -163,6 +164,10 @@ def main():
     dd.broadcast_module(idm, 0)
     torch.cuda.synchronize()
     t0 = time.time()
+    if args.parallelism == "auto":
+        planes_per_rank = args.gaussians * args.rays_per_ellipsoid * 1536 / max(world, 1)
+        fits_across = world > 1 and planes_per_rank < 0.6 * torch.cuda.get_device_properties(dev).total_memory
+        args.parallelism = "ray" if (args.scoring == "streamed" and args.mode == "full" and fits_across) else "image"
     ray_sharded = args.parallelism == "ray"
     # (--graph: the whole per-batch path -- image side, q_proj, select path with its status read deferred to the step's one D2H, pose
     # solve -- replayed as ONE hipGraph.  Measured in round 3 at 1 image per step: 26.4 ms against 13.9 ms eager with the image side alone
