@@ -672,13 +672,49 @@ def g12(m):
     save("g12_datasets", **out)
 
 
+# --------------------------------------------------------------------------------------
+# g13: what is left of pose_estimation/isocell.py -- the random modes of isocell_distribution (isrand 1..4, :47-61) and the grouping
+# helpers group_by_360_isocell / get_dirs_group_idx (:87-154).  Neither is called anywhere in the reference.  The random modes add a th0 of
+# shape [n rings] to a vector of shape [N0 n^2 cells] (:24,44): they raise RuntimeError for every target with more than one ring and only run
+# for n = 1 -- recorded here: which (target, N0, mode) raise, and the n = 1 outputs under a CPU seed.
+# --------------------------------------------------------------------------------------
+def g13(m):
+    iso = m["isocell"]
+    out, raises = {}, []
+    for mode in (1, 2, 3, 4):
+        for tgt, n0 in ((1, 1), (3, 3), (4, 1), (64, 1), (35, 3)):
+            torch.manual_seed(1300 + 10 * mode + n0)
+            try:
+                d = iso.isocell_distribution(tgt, torch.float32, "cpu", N0=n0, isrand=mode)
+                out[f"rand_m{mode}_t{tgt}_n{n0}"] = N(d)
+                raises.append([mode, tgt, n0, 0])
+            except RuntimeError:
+                raises.append([mode, tgt, n0, 1])
+    out["raises"] = np.asarray(raises, np.int64)
+    # grouping helpers on the reference's own directions (both hemispheres) and on random unit vectors
+    rng = np.random.default_rng(1313)
+    for tgt, n0 in ((27, 3), (48, 3), (64, 1)):
+        up = N(iso.isocell_distribution(tgt, torch.float32, "cpu", N0=n0, isrand=-1))
+        dirs = np.concatenate([up, up * np.array([1, 1, -1], np.float32)], 0)
+        rnd = rng.standard_normal((40, 3)).astype(np.float32)
+        rnd /= np.linalg.norm(rnd, axis=1, keepdims=True)
+        dirs = np.concatenate([dirs, rnd.astype(np.float32)], 0)
+        grp, ring, cell = iso.group_by_360_isocell(T(dirs), tgt, N0=n0)
+        out[f"grp_{tgt}_{n0}_dirs"] = dirs
+        out[f"grp_{tgt}_{n0}_group"], out[f"grp_{tgt}_{n0}_ring"], out[f"grp_{tgt}_{n0}_cell"] = N(grp), N(ring), N(cell)
+        groups = iso.get_dirs_group_idx(T(dirs), tgt, N0=n0)
+        out[f"grp_{tgt}_{n0}_sizes"] = np.asarray([g.shape[0] for g in groups], np.int64)
+        out[f"grp_{tgt}_{n0}_members"] = np.concatenate([N(g) for g in groups]) if groups else np.zeros(0, np.int64)
+    save("g13_isocell_rest", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(8)
     m = import_reference()
-    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}
+    gens = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}
     only = [x for x in args.only.split(",") if x]
     for k, fn in gens.items():
         if only and k not in only:
