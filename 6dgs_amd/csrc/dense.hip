@@ -235,7 +235,6 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   const long long prof_start = clock64();
   const long long prof_rt = wall_clock64();
 #endif
-  const int rayl = wn * 32 * NTN + (lane & 31);        // this lane's rays within the tile: rayl + 32 * tn
 // one slot: staging register P of the slab loaded during the previous iteration goes to the idle stage and is re-loaded with its piece of
 // the slab after next (a load has one full slab, ~2 us, to come back); pinned between two groups of MFMAs
 #define SDG_SLOT(J, P)                     \

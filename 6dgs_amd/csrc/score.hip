@@ -474,6 +474,7 @@ struct LogitsF16Args {
   int n_sets;
   unsigned* sib_sync;    // [n_sets] zeroed before the launch
   int sib_period;        // tiles between two meetings of a sibling set (>= 1)
+  unsigned sib_extra;    // arrivals a set waits for beyond its members: 0.  (1 = SIXDGS_SIBLING_SYNC=3, the test of the bounded wait: a sibling never shows up)
 };
 // what the kernel leaves behind for each tile
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
@@ -530,9 +531,13 @@ constexpr int kBNX = 256;                // rays per tile
 // -- only the per-tile meeting is better on every box.  Launch time by HIP events: 57.77 / 58.16 / 58.69 ms on the first box, 59.9 / 60.3 / 60.1 ms on the
 // second (under the PMC pass): the meeting costs 0.2-1.6 % (a tile takes as long as its slowest sibling), less than the boxes differ (56.5-61 ms).  The
 // re-reads themselves never cost time -- the kernel is matrix-pipe / power bound at 1.0-1.3 TB/s -- the default takes the bytes down where that is nearly free.
-// No deadlock: a set's resident members spin only until the set's other members are dispatched, which needs a free CU, which the sets whose members
-// are all resident provide by finishing (workgroups are dispatched in blockIdx order: the resident prefix consists of whole sets but one per XCD).
+// No deadlock: within ONE launch a set's resident members spin only until the set's other members are dispatched, which needs a free CU, which the sets
+// whose members are all resident provide by finishing (workgroups are dispatched in blockIdx order: the resident prefix consists of whole sets but one
+// per XCD).  Two or more sweeps in flight on one device (streams, processes) could each hold half-resident sets on all of an XCD's CUs; for that the spin
+// is bounded (kSibSpinLimit) and a set whose member gives up is released for the rest of the launch -- the launch then runs like mode 2.
 constexpr int kSiblingSyncDefault = 1;
+constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
+constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1; SIXDGS_SIB_PERIOD overrides)
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   // A.n_tiles counts 256-ray tiles here; the groups take floor(n_tiles / n_groups) tiles, the first n_tiles % n_groups one more
   const int t_base = A.n_tiles / A.n_groups, t_rem = A.n_tiles - t_base * A.n_groups;
   const int n_tiles128 = (int)((A.r + 127) >> 7);
-  unsigned sib_target = 0;                          // arrivals at sib_sync[set] after the tiles walked so far (nb per tile)
+  unsigned sib_target = PERS ? A.sib_extra : 0u;    // arrivals at sib_sync[set] after the tiles walked so far (nb per tile)
   int grp = set;
   do {                                              // PERS: the ray-tile groups set, set + n_sets, ...; otherwise the one group `set`
   float* pout = A.partial + ((int64_t)bl * A.n_groups + grp) * kT * 2;
@@ -765,10 +770,18 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
         if (wave == 0) {
           unsigned* const sp = A.sib_sync + set;
           if (lane == 0) __hip_atomic_fetch_add(sp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while (true) {
+          // The wait is BOUNDED: the meeting is a cache-locality measure, nothing reads what a sibling wrote.  A sibling that does not show up within
+          // kSibSpinLimit polls (milliseconds; a tile takes ~30 us) is not resident -- another kernel holds its CU, e.g. a second sweep on another
+          // stream or from another process, whose own half-resident sets could be waiting for OUR CUs -- and then the first member to notice releases
+          // the set for the rest of the launch (kSibReleased is beyond every target: < 2^24 arrivals per set).
+          for (int polls = 0;; ++polls) {
             unsigned seen;
             asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(sp) : "memory");
             if ((int)(seen - sib_target) >= 0) break;
+            if (polls == kSibSpinLimit) {
+              if (lane == 0) __hip_atomic_fetch_or(sp, kSibReleased, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (OR: several members may give up at once)
+              break;
+            }
             __builtin_amdgcn_s_sleep(1);
           }
         }
@@ -2119,7 +2132,7 @@ int f16x_groups(int64_t r) {
 }
 
 // CUs to spread persistent sibling sets over, or 0 = one-shot grid (SIXDGS_SIBLING_SYNC=0/1 overrides the default)
-int sibling_sync_mode() {      // 0 one-shot grid, 1 persistent sibling sets in lock-step, 2 persistent without the lock-step (measurement)
+int sibling_sync_mode() {      // 0 one-shot grid, 1 persistent sibling sets in lock-step, 2 persistent without the lock-step (measurement), 3 lock-step with a sibling that never arrives (test)
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SIXDGS_SIBLING_SYNC");
@@ -2233,6 +2246,7 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
       // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
       V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
       V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
+      V.sib_extra = sibling_sync_mode() == 3 ? 1u : 0u;
       {
         static const int period = [] { const char* e = getenv("SIXDGS_SIB_PERIOD"); const int v = e ? atoi(e) : kSibPeriod; return v >= 1 ? v : 1; }();
         V.sib_period = period;

@@ -365,3 +365,40 @@ def test_deferred_status_whole_step_graph_and_resolve(ops, syn):
         idm._select_ws = None
     assert idm.last_scoring_path == "select+two-pass(2)"
     assert torch.equal(sol["idx"], ref["idx"]) and float((c2w - ref["c2w"].cpu()).abs().max()) < 1e-6
+
+
+_CHILD = r"""
+import importlib, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ["SIXDGS_TEST_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SIXDGS_TEST_ROOT"], "tests"))
+import test_gpu_select as t
+ops = importlib.import_module("6dgs_amd.ops"); ops.set_mma_mode(ops.MMA_DEFAULT)
+c = t.make_case(ops, 300_000, 77, 6.0, [256, 200, 256, 31])
+out = None
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.time()
+    out = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=4096)
+    torch.cuda.synchronize(); dt = time.time() - t0
+np.savez(sys.argv[1], idx=out[0].cpu().numpy(), val=out[1].cpu().numpy(), status=out[2].cpu().numpy(), seconds=dt)
+"""
+
+
+def test_sibling_meeting_gives_up_on_a_member_that_never_arrives(ops, tmp_path):
+    """The per-tile meeting of a persistent sibling set is a cache-locality measure with a BOUNDED wait (score.hip, kSibSpinLimit): with
+    SIXDGS_SIBLING_SYNC=3 every set waits for one arrival more than it has members -- what a second sweep holding the CUs of half a set looks
+    like -- and must release itself after the limit and return the same result, in bounded time."""
+    import subprocess
+    outs = {}
+    for mode in ("3", "0"):
+        f = str(tmp_path / f"m{mode}.npz")
+        env = dict(os.environ, SIXDGS_SIBLING_SYNC=mode, SIXDGS_TEST_ROOT=ROOT)
+        p = subprocess.run([sys.executable, "-W", "ignore", "-c", _CHILD, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[mode] = np.load(f)
+    a, b = outs["3"], outs["0"]
+    assert (a["status"] >= 0).all() and np.array_equal(a["status"] >= 0, b["status"] >= 0)
+    assert np.array_equal(a["idx"], b["idx"]) and np.allclose(a["val"], b["val"], rtol=1e-6, atol=0)
+    assert float(a["seconds"]) < 2.0, float(a["seconds"])          # 64 sets give up once each, concurrently: tens of milliseconds
+    c = make_case(ops, 300_000, 77, 6.0, [256, 200, 256, 31])      # and the default layout (lock-step, everyone arrives) in this process
+    idx, val, st = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=4096)
+    assert np.array_equal(idx.cpu().numpy(), b["idx"])
