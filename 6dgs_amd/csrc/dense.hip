@@ -24,25 +24,24 @@ using namespace sdg;
 
 namespace {
 
-#ifndef SDG_TILE_MAJOR
-#define SDG_TILE_MAJOR 0
-#endif
-// Layout of the chain's ACTIVATION planes in HBM.  Ray-major [ray][slab][128 B] (the default) makes every operand load a set of
-// 128-byte pieces 640 B .. 2 KB apart and every output store 512-byte pieces 2 KB apart.  Round 3 built the alternative, tile-major
-// [granule of 128 rays][slab][ray in granule][128 B] (-DSDG_TILE_MAJOR=1): a granule's share of a slab is 16 KB of consecutive bytes,
-// an epilogue unit writes 64 KB of consecutive bytes, a tile's working set is one 512 KB run -- and measured the SAME time to 0.3 %
-// (293 vs 294 TFLOP/s, with and without a per-granule pad against channel aliasing): the chain is not bound by the DRAM access
-// pattern.  (The first tile-major build ran at 172 TFLOP/s -- 112 spilled registers, not memory; see the epilogue's opaque copies.)
-constexpr bool kTileMajor = SDG_TILE_MAJOR != 0;
-constexpr int kGran = 128;            // rays per granule
+// Layout of the chain's ACTIVATION planes in HBM: two forms, chosen per process (SIXDGS_DENSE_CM, see dense_chunk_major()).
+//   ray-major   [ray][slab][plane h 64 B | plane l 64 B] (rounds 2-3): an operand load is a set of 128-byte pieces 640 B .. 2 KB apart, and
+//               a lane of the MFMA result (one ray, 4 consecutive features) owns 8-byte pieces of its ray's row, so the epilogue goes through
+//               an LDS staging tile (two barriers per (block, 128-ray half)) to write 512-byte pieces.
+//   chunk-major [granule of 128 rays][slab][plane 2][16-byte chunk 4][ray 128][16 B] (round 3, last change): the same 16 KB per (granule,
+//               slab), with the 8 features of a chunk of 128 consecutive rays adjacent.  With the rows of the layer's weights permuted so
+//               that a lane's registers hold 8 CONSECUTIVE features (dense_row_perm), a lane owns whole 16-byte chunks and a wave
+//               instruction of the epilogue writes 2 x 512 consecutive bytes STRAIGHT from the accumulator registers: no staging tile, no
+//               barriers behind the block maxima.  The consumer's loads are 1 KB of consecutive bytes per wave instruction (64 rays of one
+//               chunk), written into the same LDS image as before.
+// (Round 3 also measured a tile-major form [granule][slab][ray][128 B] -- same time as ray-major to 0.3 %, removed again)
+constexpr int kGran = 128;               // rays per granule
 constexpr int kGranSlab = kGran * 128;   // bytes of one (granule, slab)
-#ifndef SDG_GRAN_PAD
-#define SDG_GRAN_PAD 4352
-#endif
-// Tile-major only: every granule is followed by kGranPad unused bytes, so that the granules of different tiles do not start at
-// addresses congruent modulo a power of two (channel aliasing between workgroups that walk their slabs in step).  Measured: no effect.
-constexpr int kGranPad = kTileMajor ? SDG_GRAN_PAD : 0;
-__host__ __device__ constexpr int64_t gran_stride(int ks) { return (int64_t)ks * kGranSlab + kGranPad; }
+constexpr int kChunkRun = kGran * 16;    // bytes of one (granule, slab, plane, chunk): 128 rays x 16 B
+// Chunk-major layers permute the 32 rows of every MFMA row block: MFMA row m = 8 rg + 4 h + j (register group rg, lane half h, register j)
+// computes feature pi(m) = 16 (rg >> 1) + 8 h + 4 (rg & 1) + j of the block (bits 2 and 3 of m swapped; an involution), so that lane half h
+// holds the features 16 p + 8 h + 0..7 -- chunk 2 p + h of the 32-feature slab -- in its register groups 2 p and 2 p + 1.
+__host__ __device__ constexpr int dense_row_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
 constexpr int kSlabB = 128;           // bytes of one (row, slab): plane h 64 B, plane l 64 B
 constexpr int kPRow = 144;            // LDS row stride of a staged slab
 constexpr int kStRow = 528;           // staging row of the epilogue: 512 B of a ray + 16 B (with 512 the 32 lanes of a write hit one bank: 32-way conflict)
@@ -71,6 +70,7 @@ struct DenseArgs {
   int64_t ldo;
   int relu;
   unsigned* out_norm_max; // or null (with out_tile_inv): *out_norm_max = max(*out_norm_max, bit pattern of max over the rays of |key row|, rounded up)
+  int cm_in, cm_out;     // the input / output planes are chunk-major (cm_out: with out_planes and without out_tile_inv; the weight rows are permuted)
   float* out_tile_inv;   // or null.  Non-null (with out_planes, N = 384): the planes are the SCORER's key planes -- one power-of-two scale per
                          // tile of 128 rays (largest magnitude in [2^13, 2^14)), out_tile_inv[tile] = its reciprocal; out_shift is not written
 };
@@ -103,7 +103,8 @@ constexpr int kWStage = kWRows * kPRow;        // 73 728 B
 // slab after next -- and a wave runs from a slab's last MFMA straight into the next slab's fragment reads.
 // Epilogue per pass: bias, ReLU, per-(ray, 128-feature block) power-of-two scale, fp16 split (all waves, in place), then per (block,
 // 128-ray half) LDS staging and coalesced 16-byte stores through the stage just consumed.
-template <int NTM, int NTN>
+// INCM / OUTCM: the input / output activation planes are chunk-major (above); OUTCM also means the layer's weight rows are permuted.
+template <int NTM, int NTN, bool INCM, bool OUTCM>
 __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n_pass, unsigned total_tiles, unsigned split) {
   constexpr int FP = 128 * NTM;          // features per pass
   constexpr int RT = 64 * NTN;           // rays per tile
@@ -156,7 +157,10 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 8 instructions x 64
   // rows per slab.  A load's address is a uniform base (scalar unit) + a 32-bit offset, three VALU operations per load; loads are
   // unconditional with clamped rows.
-  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16, t16 = (unsigned)tid * 16u;
+  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16;
+  const unsigned rm_dst = lrow * kPRow + lc16;                                          // LDS offsets of this thread's pieces within a stage
+  const unsigned cm_lane = (unsigned)tid & 63u, cm_chunk = ((unsigned)tid >> 6) * (unsigned)kChunkRun;
+  const unsigned cm_dst = cm_lane * kPRow + ((unsigned)tid >> 6) * 16u;
   unsigned lt = tile, lb = 0;      // load cursor: tile, pass and slab of the next fetch
   int ls = 0;
   const char *abase0, *abase1;
@@ -164,8 +168,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #define SDG_TILEBASE()                                                                   \
   {                                                                                      \
     const int64_t r0_ = (int64_t)lt * RT;                                                \
-    abase0 = kTileMajor ? A.a0 + (r0_ >> 7) * gran_stride(A.ks0) : A.a0 + (r0_ * A.ks0) * kSlabB;                           \
-    abase1 = A.a1 ? (kTileMajor ? A.a1 + (r0_ >> 7) * gran_stride(A.ks1) : A.a1 + (r0_ * A.ks1) * kSlabB) : abase0;         \
+    abase0 = INCM ? A.a0 + (r0_ >> 7) * A.ks0 * kGranSlab : A.a0 + (r0_ * A.ks0) * kSlabB;                                   \
+    abase1 = A.a1 ? (INCM ? A.a1 + (r0_ >> 7) * A.ks1 * kGranSlab : A.a1 + (r0_ * A.ks1) * kSlabB) : abase0;                 \
     lrmax = (unsigned)min((int64_t)(RT - 1), A.m - 1 - r0_);                             \
   }
   SDG_TILEBASE()
@@ -173,19 +177,27 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #define SDG_BASES()                                                                                                       \
   const char* wbase = A.wp + (unsigned)ls * kSlabB;                                                                       \
   const bool seg1_ = ls >= A.ks0;                                                                                         \
-  const unsigned sstep_ = kTileMajor ? (unsigned)kGranSlab : (unsigned)kSlabB;                                            \
+  const unsigned sstep_ = INCM ? (unsigned)kGranSlab : (unsigned)kSlabB;                                                  \
   const char* abase = seg1_ ? abase1 + (unsigned)(ls - A.ks0) * sstep_ : abase0 + (unsigned)ls * sstep_;                  \
-  const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * sstep_ + (unsigned)kGranPad, wstride = (unsigned)ks * kSlabB; \
+  const unsigned astride = (unsigned)(seg1_ ? A.ks1 : A.ks0) * sstep_, wstride = (unsigned)ks * kSlabB;                   \
   const unsigned wrow0 = (pbase + lb) * (unsigned)FP, wrmax = (unsigned)A.n - 1u;
-// ray rows of a slab.  Ray-major: row * astride (clamped to the tile's last valid ray).  Tile-major: row = 64 j + (tid >> 3) sits in
-// granule j >> 1 at ((j & 1) 64 + (tid >> 3)) 128 + (tid & 7) 16 = (j & 1) 8192 + 16 tid -- ONE register (t16) plus compile-time and
-// uniform terms; a row beyond the tile's last valid ray reads row 0 of the tile instead (a duplicate of a valid ray, never stored).
+// ray rows of a slab.  Ray-major: thread (row lrow of 64, chunk tid & 7) reads row * astride (astride = bytes per ray), clamped to the tile's
+// last valid ray.  Chunk-major: wave w reads chunk (plane w >> 2, k-chunk w & 3) of the piece's 64 rays, lane = ray: 1 KB of consecutive bytes
+// per wave instruction; astride = bytes per granule; a ray beyond the tile's last valid one reads that one instead (same run of bytes).
 #define SDG_LOAD(J, P)                                                                                                    \
-  P = *reinterpret_cast<const uint4*>((J) < kWL ? wbase + (min(wrow0 + 64u * (J) + lrow, wrmax) * wstride + lc16)         \
-      : !kTileMajor ? abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16)                                     \
-      : abase + ((64u * ((J) - kWL) + lrow <= lrmax) ? t16 + (unsigned)((((J) - kWL) & 1) * 8192) + (unsigned)(((J) - kWL) >> 1) * astride : lc16));
+  if ((J) < kWL) {                                                                                                        \
+    P = *reinterpret_cast<const uint4*>(wbase + (min(wrow0 + 64u * (J) + lrow, wrmax) * wstride + lc16));                 \
+  } else if (!INCM) {                                                                                                     \
+    P = *reinterpret_cast<const uint4*>(abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));                 \
+  } else {                                                                                                                \
+    const unsigned rl_ = min(64u * ((J) - kWL) + cm_lane, lrmax);                                                         \
+    P = *reinterpret_cast<const uint4*>(abase + ((rl_ >> 7) * astride + (rl_ & 127u) * 16u + cm_chunk));                  \
+  }
 #define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
-#define SDG_WRITE(DST, J, P) *reinterpret_cast<uint4*>((DST) + (J) * 64 * kPRow) = P;
+// LDS image of a slab (both layouts): row r (weights 0 .. FP-1, rays FP ..) at r * kPRow: [plane h 64 B | plane l 64 B].  DST = the stage's
+// base; weights and ray-major rays: thread (lrow, chunk tid & 7); chunk-major rays: thread (ray = lane, chunk = wave)
+#define SDG_WRITE(DST, J, P)                                                                                              \
+  *reinterpret_cast<uint4*>((DST) + (((J) >= kWL && INCM) ? cm_dst + (FP + 64 * ((J) - kWL)) * kPRow : rm_dst + (J) * 64 * kPRow)) = P;
 #define SDG_WRITE_ALL(DST) SDG_WRITE(DST, 0, p0) SDG_WRITE(DST, 1, p1) SDG_WRITE(DST, 2, p2) SDG_WRITE(DST, 3, p3) SDG_WRITE(DST, 4, p4) SDG_WRITE(DST, 5, p5) SDG_WRITE(DST, 6, p6) SDG_WRITE(DST, 7, p7)
 // past the last tile the cursor stays on the last tile's last pass (harmless re-reads)
 #define SDG_ADVANCE()                                     \
@@ -207,7 +219,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
     SDG_ADVANCE()
   }
   {
-    char* const dw0 = smem + lrow * kPRow + lc16;
+    char* const dw0 = smem;
     SDG_WRITE_ALL(dw0)
   }
   {
@@ -252,7 +264,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
       shifts_pending = false;
     }
     SDG_BASES()
-    char* dw = smem + (buf ^ 1) * kWStage + lrow * kPRow + lc16;
+    char* dw = smem + (buf ^ 1) * kWStage;
     if ((s & 3) == 0 && s > 0) {       // a new 128-input block: accumulators to its scale (exact powers of two)
       unsigned t_ = threadIdx.x;      // opaque copy: computed from it, the address is formed HERE (hoisted out of the loop it was spilled, and
       asm volatile("" : "+v"(t_));    // the scratch reload's wait drained the operand loads in flight every fourth slab)
@@ -326,7 +338,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       const bool planes_out = A.out_f32 == nullptr;
       {
-        // lane_e: rays rayl_e + 32 tn, features (of the pass) tm*128 + wm_e*32 + 8*(r>>2) + 4*(lane_e>>5) + (r&3); acc becomes the layer output in
+        // lane_e: rays rayl_e + 32 tn, features (of the pass) tm*128 + wm_e*32 + 8*(r>>2) + 4*(lane_e>>5) + (r&3) -- with permuted weight rows
+        // (OUTCM) tm*128 + wm_e*32 + dense_row_perm(the same) = .. + 16*(r>>3) + 8*(lane_e>>5) + 4*((r>>2)&1) + (r&3); acc becomes the layer output in
         // place.  All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed
         // fp32 multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value.
         const int glast = (ks - 1) >> 2;
@@ -341,7 +354,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           for (int tn = 0; tn < NTN; ++tn) rmax[tn] = 0.f;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int fl4 = f0 + tm * 128 + wm_e * 32 + 8 * rg + 4 * (lane_e >> 5);
+            const int fl4 = f0 + tm * 128 + wm_e * 32 + (OUTCM ? 16 * (rg >> 1) + 8 * (lane_e >> 5) + 4 * (rg & 1) : 8 * rg + 4 * (lane_e >> 5));
             const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + kMaxN + fl4);
             const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
             const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
@@ -442,6 +455,26 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
             }
           }
       }
+      if constexpr (OUTCM) {
+        // chunk-major planes, straight from the registers: register groups 2 p and 2 p + 1 of a lane hold the 8 features of chunk 2 p + h of the
+        // wave's slab (permuted weight rows), as 16 B of plane h and 16 B of plane l; lanes 0..31 / 32..63 of a store cover 32 consecutive rays
+        // of chunk 2 p / 2 p + 1: two runs of 512 consecutive bytes per wave instruction.  No staging tile, no further barrier.
+        const int nslab_out = A.n >> 5;
+#pragma unroll
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NTN; ++tn) {
+            const int64_t gr = ray0 + rayl_e + 32 * tn;
+            if (gr < A.m) {
+              char* const ob = A.out_planes + ((gr >> 7) * nslab_out + ((f0 >> 5) + tm * 4 + wm_e)) * (int64_t)kGranSlab + (lane_e >> 5) * kChunkRun + (gr & 127) * 16;
+#pragma unroll
+              for (int pp = 0; pp < 2; ++pp) {
+                *reinterpret_cast<float4*>(ob + (2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp], acc[tm][tn][8 * pp + 1], acc[tm][tn][8 * pp + 4], acc[tm][tn][8 * pp + 5]};
+                *reinterpret_cast<float4*>(ob + (4 + 2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp + 2], acc[tm][tn][8 * pp + 3], acc[tm][tn][8 * pp + 6], acc[tm][tn][8 * pp + 7]};
+              }
+            }
+          }
+      } else {
 #pragma unroll
       for (int tm = 0; tm < NTM; ++tm) {                    // unit = (128-feature block tm, 128-ray half): its waves fill the staging tile
         for (int hsel = 0; hsel < RT / 128; ++hsel) {
@@ -477,7 +510,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
               if (rbase + ray < A.m)
                 *reinterpret_cast<float4*>(A.out_f32 + (rbase + ray) * A.ldo + fb + c * 4) = reinterpret_cast<const float4*>(stg + ray * kStRow)[c];
             }
-          } else if (!kTileMajor || tile_mode) {      // ray-major rows: the scorer's key planes [ray][12 slabs][128 B] (and the round-2 layout)
+          } else {      // ray-major rows: the round-2 activation layout, and the scorer's key planes [ray][12 slabs][128 B]
             const int nslab_out = A.n >> 5;
 #pragma unroll
             for (int i = (int)te; i < 128 * 32; i += 512) {
@@ -485,20 +518,10 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
               if (rbase + ray < A.m)
                 *reinterpret_cast<uint4*>(A.out_planes + ((rbase + ray) * nslab_out + (fb >> 5)) * kSlabB + c * 16) = reinterpret_cast<const uint4*>(stg + ray * kStRow)[c];
             }
-          } else {
-            // tile-major: the unit's four slabs are 4 x 16 KB of CONSECUTIVE bytes; thread t moves bytes [16 t + 8192 it, + 16) of them for
-            // it = 0 .. 7: slab it >> 1, ray (t >> 3) + 64 (it & 1), chunk t & 7 of the staged tile
-            const int nslab_out = A.n >> 5;
-            char* const gb = A.out_planes + (rbase >> 7) * gran_stride(nslab_out) + (fb >> 5) * (int64_t)kGranSlab + te * 16u;
-            const char* const sb = stg + (te >> 3) * kStRow + (te & 7u) * 16;
-            const int64_t left = A.m - rbase - (te >> 3);      // this thread's rays (t >> 3) and (t >> 3) + 64 exist while left > 0 / > 64
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-              if (left > 64 * (it & 1))
-                *reinterpret_cast<uint4*>(gb + it * 8192) = *reinterpret_cast<const uint4*>(sb + (it & 1) * 64 * kStRow + (it >> 1) * kSlabB);
           }
           __syncthreads();
         }
+      }
       }
       SDG_T(te_)
       SDG_ACC(1, t1_, te_)
@@ -547,7 +570,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 // reach 1e5 rad), staged as fp32 in LDS [ray][161] (odd stride: consecutive rays on consecutive banks), then split 8 inputs at a time.
 constexpr int kEncRays = 64;
 __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restrict__ ori, const float* __restrict__ dir, const float* __restrict__ rgb,
-                                                           int64_t R, char* __restrict__ xp, int* __restrict__ xs) {
+                                                           int64_t R, char* __restrict__ xp, int* __restrict__ xs, int chunk_major) {
   __shared__ float X[kEncRays][161];
   __shared__ float src[kEncRays][9];      // p, d, c
   const int tid = threadIdx.x;
@@ -576,8 +599,11 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
     X[r][col + 3 * F] = cs;
   }
   __syncthreads();
-  for (int i = tid; i < n * 20; i += 256) {
-    const int r = i / 20, g8 = i - r * 20;
+  // 8 inputs -> one 16-byte chunk of plane h and one of plane l.  Ray-major: consecutive threads take the 20 chunks of a ray; chunk-major:
+  // consecutive threads take the same chunk of consecutive rays (their 16-byte pieces are adjacent in that layout)
+  for (int i = tid; i < kEncRays * 20; i += 256) {
+    const int r = chunk_major ? i % kEncRays : i / 20, g8 = chunk_major ? i / kEncRays : i % 20;
+    if (r >= n) continue;
     float m = 1.f;
 #pragma unroll
     for (int a = 0; a < 9; ++a) m = fmaxf(m, fabsf(src[r][a]));
@@ -592,21 +618,22 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
       l[e] = (_Float16)(x - (float)hh);
     }
     const int64_t gr = ray0 + r;
-    char* dst = kTileMajor ? xp + (gr >> 7) * gran_stride(5) + (((g8 >> 2)) * kGran + (gr & 127)) * kSlabB + (g8 & 3) * 16
-                           : xp + (gr * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
+    char* const dst = chunk_major ? xp + ((gr >> 7) * 5 + (g8 >> 2)) * kGranSlab + (g8 & 3) * kChunkRun + (gr & 127) * 16
+                                  : xp + (gr * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
     *reinterpret_cast<f16x8_t*>(dst) = h;
-    *reinterpret_cast<f16x8_t*>(dst + 64) = l;
+    *reinterpret_cast<f16x8_t*>(dst + (chunk_major ? 4 * kChunkRun : 64)) = l;
     if (g8 == 0) { xs[2 * (ray0 + r)] = sh; xs[2 * (ray0 + r) + 1] = sh; }
   }
 }
 
 // weights fp32 [n][ld] (columns c0 .. c0 + kcols of every row; zero beyond) -> planes [n][ks_total][128 B] at slab offset s_off, scaled by
-// the row's power of two f3_scale(wmax[row])
+// the row's power of two f3_scale(wmax[row]); perm: plane row (row & ~31) + m holds feature (row & ~31) + dense_row_perm(m)
 __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__ src, int n, int64_t ld, int c0, int kcols, int kslabs, const float* __restrict__ wmax,
-                                                       char* __restrict__ dst, int ks_total, int s_off) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (row, group of 8 columns)
+                                                       char* __restrict__ dst, int ks_total, int s_off, int perm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (plane row, group of 8 columns)
   if (i >= n * kslabs * 4) return;
-  const int row = i / (kslabs * 4), g8 = i - row * (kslabs * 4);
+  const int prow = i / (kslabs * 4), g8 = i - prow * (kslabs * 4);
+  const int row = perm ? (prow & ~31) | dense_row_perm(prow & 31) : prow;
   const float sc = f3_scale(wmax[row]);
   f16x8_t h, l;
 #pragma unroll
@@ -617,12 +644,21 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
     h[e] = hh;
     l[e] = (_Float16)(x - (float)hh);
   }
-  char* d = dst + ((int64_t)row * ks_total + s_off + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
+  char* d = dst + ((int64_t)prow * ks_total + s_off + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
   *reinterpret_cast<f16x8_t*>(d) = h;
   *reinterpret_cast<f16x8_t*>(d + 64) = l;
 }
 
 bool g_dense_no_split = getenv("SIXDGS_DENSE_NO_SPLIT") != nullptr;      // developer switch: the round-2 form (both passes in one workgroup)
+// The chain's activation layout of this process: chunk-major unless SIXDGS_DENSE_CM=0 (ray-major, rounds 2-3).  One per process, because the
+// weight planes are packed once (sixdgs_pack_scorer_weights) with or without the row permutation that goes with it.  Both layouts give the
+// same keys bit for bit (same MFMA order per output, same scales; tools/cm_check.py, test_chain_layouts_give_identical_keys); chunk-major is
+// 3-4 % faster (290 -> 302 TFLOP/s fp32-equivalent, 8 M rays, alternating runs on one box; profiles/r03_chain_chunk_major.log).
+constexpr bool kChunkMajorDefault = true;
+bool dense_chunk_major() {
+  static const bool on = [] { const char* e = getenv("SIXDGS_DENSE_CM"); return e ? atoi(e) != 0 : kChunkMajorDefault; }();
+  return on;
+}
 
 int dense_grid(int64_t tiles) {
   static int cus = 0;      // one persistent workgroup per compute unit (the kernel's 156 KB of LDS allow one)
@@ -649,8 +685,18 @@ int launch_dense(const DenseArgs& A, hipStream_t s) {
   int grid = dense_grid(split ? 2 * tiles : tiles);
   if (grid <= 0) return (int)hipErrorInvalidDevice;
   if (split) grid &= ~1;                       // sibling pairs
-  if (wide) hipLaunchKernelGGL((k_dense_planes<3, 2>), dim3((unsigned)grid), dim3(512), 0, s, A, n_pass, (unsigned)tiles, 0u);
-  else hipLaunchKernelGGL((k_dense_planes<2, 4>), dim3((unsigned)grid), dim3(512), 0, s, A, n_pass, (unsigned)tiles, split);
+  if (A.cm_out && (!A.out_planes || A.out_tile_inv || !A.cm_in)) return SIXDGS_E_BADARG;
+  const dim3 g((unsigned)grid), b(512);
+  const unsigned nt = (unsigned)tiles;
+  if (wide) {
+    if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<3, 2, true, true>), g, b, 0, s, A, n_pass, nt, 0u);
+    else if (A.cm_in) hipLaunchKernelGGL((k_dense_planes<3, 2, true, false>), g, b, 0, s, A, n_pass, nt, 0u);
+    else hipLaunchKernelGGL((k_dense_planes<3, 2, false, false>), g, b, 0, s, A, n_pass, nt, 0u);
+  } else {
+    if (A.cm_in != A.cm_out) return SIXDGS_E_BADARG;      // (the N = 512 layers are inner layers)
+    if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<2, 4, true, true>), g, b, 0, s, A, n_pass, nt, split);
+    else hipLaunchKernelGGL((k_dense_planes<2, 4, false, false>), g, b, 0, s, A, n_pass, nt, split);
+  }
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -666,54 +712,56 @@ namespace sdg {
 size_t dense_weight_plane_bytes() { return (size_t)(512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12) * kSlabB; }
 
 int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipStream_t s) {
-  struct L { const float* src; int n; int64_t ld; int c0, kcols, kslabs; const float* wmax; int ks_total, s_off; size_t off; };
+  struct L { const float* src; int n; int64_t ld; int c0, kcols, kslabs; const float* wmax; int ks_total, s_off; size_t off; int perm; };
+  const int pm = dense_chunk_major() ? 1 : 0;      // the layers that WRITE chunk-major planes (all but k_proj) have their rows permuted
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
                ok = o4 + (size_t)384 * 16 * kSlabB;
   const L layers[] = {
-      {w->w1, 512, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, 5, w->m1, 5, 0, o1},
-      {w->w2, 512, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m2, 16, 0, o2},
-      {w->w3, 512, SIXDGS_HID + SIXDGS_RAY_IN_PAD, 0, SIXDGS_HID, 16, w->m3, 21, 0, o3},                     // [h2 | x]: the h2 columns ...
-      {w->w3, 512, SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID, SIXDGS_RAY_IN_PAD, 5, w->m3, 21, 16, o3},     // ... then the x columns, padded to 5 slabs
-      {w->w4, 384, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m4, 16, 0, o4},
-      {w->wk, 384, SIXDGS_D, 0, SIXDGS_D, 12, w->mk, 12, 0, ok},
+      {w->w1, 512, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, 5, w->m1, 5, 0, o1, pm},
+      {w->w2, 512, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m2, 16, 0, o2, pm},
+      {w->w3, 512, SIXDGS_HID + SIXDGS_RAY_IN_PAD, 0, SIXDGS_HID, 16, w->m3, 21, 0, o3, pm},                     // [h2 | x]: the h2 columns ...
+      {w->w3, 512, SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID, SIXDGS_RAY_IN_PAD, 5, w->m3, 21, 16, o3, pm},     // ... then the x columns, padded to 5 slabs
+      {w->w4, 384, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m4, 16, 0, o4, pm},
+      {w->wk, 384, SIXDGS_D, 0, SIXDGS_D, 12, w->mk, 12, 0, ok, 0},
   };
   for (const L& l : layers)
     hipLaunchKernelGGL(k_weight_planes, dim3((unsigned)sdg_cdiv((int64_t)l.n * l.kslabs * 4, 256)), dim3(256), 0, s, l.src, l.n, l.ld, l.c0, l.kcols, l.kslabs,
-                       l.wmax, planes + l.off, l.ks_total, l.s_off);
+                       l.wmax, planes + l.off, l.ks_total, l.s_off, l.perm);
   SDG_LAUNCH_OK();
   return 0;
 }
 
-size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 4 + 4) * sizeof(int) + (3 * (size_t)kGranPad + kGran - 1) / kGran; }
+size_t dense_chain_bytes_per_ray() { return 5 * kSlabB + 2 * 16 * kSlabB + (2 + 4 + 4) * sizeof(int); }
 
 // ori/dir/rgb of m rays -> fp32 keys kdst [m][384] (row stride 384).  ws: dense_chain_bytes_per_ray() * (m rounded up to 128) bytes, 256-B aligned.
 int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m, const sixdgs_scorer_weights* w, const char* wplanes, float* kdst, char* kplanes,
                 float* kinv, float* knorm_max, char* ws, hipStream_t s) {
-  const size_t mp = (size_t)sdg_cdiv(m, kGran) * kGran;      // the plane buffers hold whole granules of 128 rays (tile-major layout)
+  const size_t mp = (size_t)sdg_cdiv(m, kGran) * kGran;      // the plane buffers hold whole granules of 128 rays (either layout: 128 B per ray and slab)
   const size_t ng = mp / kGran;
+  const int cm = dense_chunk_major() ? 1 : 0;
   char* xp = ws;
-  char* hp1 = xp + ng * (size_t)(5 * kGranSlab + kGranPad);
-  char* hp2 = hp1 + ng * (size_t)(16 * kGranSlab + kGranPad);
-  int* xs = reinterpret_cast<int*>(hp2 + ng * (size_t)(16 * kGranSlab + kGranPad));
+  char* hp1 = xp + ng * (size_t)(5 * kGranSlab);
+  char* hp2 = hp1 + ng * (size_t)(16 * kGranSlab);
+  int* xs = reinterpret_cast<int*>(hp2 + ng * (size_t)(16 * kGranSlab));
   int* sa = xs + 2 * mp;
   int* sb = sa + 4 * mp;
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
                ok = o4 + (size_t)384 * 16 * kSlabB;
-  hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs);
+  hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs, cm);
   int st;
-  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr, nullptr};
+  DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l1, s))) return st;
-  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr, nullptr};
+  DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l2, s))) return st;
-  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr, nullptr};
+  DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l3, s))) return st;
   // layer 4 has 384 outputs: 3 blocks; its planes reuse hp2 with 12 slabs per ray
-  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr, nullptr};
+  DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l4, s))) return st;
   // k_proj: fp32 keys, or (kplanes) straight the scorer's key planes -- a 128-ray tile of the 384 x 128 shape IS a key tile, so the split
   // kernel and the fp32 keys' trip through HBM drop out
   DenseArgs l5 = {wplanes + ok, w->mk, w->bk, hp2, sb, nullptr, nullptr, 12, 0, 3, 0, m, 384, kplanes, nullptr, kplanes ? nullptr : kdst, SIXDGS_D, 0,
-                  kplanes ? reinterpret_cast<unsigned*>(knorm_max) : nullptr, kplanes ? kinv : nullptr};
+                  kplanes ? reinterpret_cast<unsigned*>(knorm_max) : nullptr, cm, 0, kplanes ? kinv : nullptr};
   return launch_dense(l5, s);
 }
 

@@ -23,7 +23,7 @@ from .backbone import BackboneWrapper, BatchedTokens
 from .camera_direction_network import CameraDirectionPredictor
 
 
-def _lib_ray_keys_ws(r: int, max_chunk: int = 262144) -> int:
+def _lib_ray_keys_ws(r: int, max_chunk: int = ops.RAY_KEYS_CHUNK) -> int:
     from . import _lib
     return int(_lib.load().sixdgs_ray_keys_workspace_bytes(int(r), int(max_chunk)))
 

@@ -5,6 +5,7 @@ Tolerances are stated per test.  Integer / index / boolean results must be ident
 documented floating-point tie boundaries (arc-length table look-ups within one ulp of an entry).
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -742,3 +743,18 @@ def test_plane_chain_randomised_sizes_and_chunks(ops, syn):
             assert bool(torch.isfinite(key).all())
     finally:
         ops.set_mma_mode(prev)
+
+
+def test_chain_layouts_give_identical_keys(tmp_path):
+    """The plane-to-plane chain keeps its activations chunk-major (default) or ray-major (SIXDGS_DENSE_CM=0; one layout per process, the weight
+    planes are packed for it).  Same MFMA order per output and same scales: the key planes, tile scales, fp32 keys and the key-norm maximum of
+    the two are bit-identical, ragged tiles and chunked runs included (tools/cm_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = str(tmp_path / "ray_major.pt")
+    for mode, args in (("0", ["save", f]), ("1", ["compare", f])):
+        p = subprocess.run([sys.executable, "-W", "ignore", os.path.join(root, "tools", "cm_check.py"), *args], env=dict(os.environ, SIXDGS_DENSE_CM=mode),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    assert "CM_CHECK PASS" in p.stdout
