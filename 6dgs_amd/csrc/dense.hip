@@ -18,6 +18,7 @@
 #include "gemm_kernel.h"
 #include "device_math.h"
 #include "dense.h"
+#include "dense_layout.h"
 #include <cstdlib>
 
 using namespace sdg;
@@ -30,20 +31,17 @@ namespace {
 //               an LDS staging tile (two barriers per (block, 128-ray half)) to write 512-byte pieces.
 //   chunk-major [granule of 128 rays][slab][plane 2][16-byte chunk 4][ray 128][16 B] (round 3, last change): the same 16 KB per (granule,
 //               slab), with the 8 features of a chunk of 128 consecutive rays adjacent.  With the rows of the layer's weights permuted so
-//               that a lane's registers hold 8 CONSECUTIVE features (dense_row_perm), a lane owns whole 16-byte chunks and a wave
+//               that a lane's registers hold 8 CONSECUTIVE features (dl::row_perm), a lane owns whole 16-byte chunks and a wave
 //               instruction of the epilogue writes 2 x 512 consecutive bytes STRAIGHT from the accumulator registers: no staging tile, no
 //               barriers behind the block maxima.  The consumer's loads are 1 KB of consecutive bytes per wave instruction (64 rays of one
 //               chunk), written into the same LDS image as before.
 // (Round 3 also measured a tile-major form [granule][slab][ray][128 B] -- same time as ray-major to 0.3 %, removed again)
-constexpr int kGran = 128;               // rays per granule
-constexpr int kGranSlab = kGran * 128;   // bytes of one (granule, slab)
-constexpr int kChunkRun = kGran * 16;    // bytes of one (granule, slab, plane, chunk): 128 rays x 16 B
-// Chunk-major layers permute the 32 rows of every MFMA row block: MFMA row m = 8 rg + 4 h + j (register group rg, lane half h, register j)
-// computes feature pi(m) = 16 (rg >> 1) + 8 h + 4 (rg & 1) + j of the block (bits 2 and 3 of m swapped; an involution), so that lane half h
-// holds the features 16 p + 8 h + 0..7 -- chunk 2 p + h of the 32-feature slab -- in its register groups 2 p and 2 p + 1.
-__host__ __device__ constexpr int dense_row_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }
-constexpr int kSlabB = 128;           // bytes of one (row, slab): plane h 64 B, plane l 64 B
-constexpr int kPRow = 144;            // LDS row stride of a staged slab
+// (constants and index arithmetic of both layouts: dense_layout.h, shared with the CPU test-suite)
+using dl::kGran;
+using dl::kGranSlab;
+using dl::kChunkRun;
+using dl::kSlabB;
+using dl::kPRow;
 constexpr int kStRow = 528;           // staging row of the epilogue: 512 B of a ray + 16 B (with 512 the 32 lanes of a write hit one bank: 32-way conflict)
 constexpr int kShMax = 40;            // activation shifts are clamped to +-40: the rescale between blocks stays far from overflow
 
@@ -157,10 +155,10 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   // loader: 8 lanes x 16 B cover the 128 bytes of one (row, slab): every wave instruction reads 8 full cache lines; 8 instructions x 64
   // rows per slab.  A load's address is a uniform base (scalar unit) + a 32-bit offset, three VALU operations per load; loads are
   // unconditional with clamped rows.
-  const unsigned lrow = tid >> 3, lc16 = (tid & 7) * 16;
-  const unsigned rm_dst = lrow * kPRow + lc16;                                          // LDS offsets of this thread's pieces within a stage
-  const unsigned cm_lane = (unsigned)tid & 63u, cm_chunk = ((unsigned)tid >> 6) * (unsigned)kChunkRun;
-  const unsigned cm_dst = cm_lane * kPRow + ((unsigned)tid >> 6) * 16u;
+  const unsigned lrow = dl::load_ray(false, (unsigned)tid, 0), lc16 = dl::load_chunk8(false, (unsigned)tid) * 16u;      // weights and ray-major rays
+  const unsigned rm_dst = dl::lds_offset(lrow, 0, 0) + lc16;                            // LDS offsets of this thread's pieces within a stage
+  const unsigned cm_lane = dl::load_ray(true, (unsigned)tid, 0), cm_chunk = dl::load_chunk8(true, (unsigned)tid) * (unsigned)kChunkRun;
+  const unsigned cm_dst = dl::lds_offset(cm_lane, 0, 0) + dl::load_chunk8(true, (unsigned)tid) * 16u;
   unsigned lt = tile, lb = 0;      // load cursor: tile, pass and slab of the next fetch
   int ls = 0;
   const char *abase0, *abase1;
@@ -191,7 +189,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
     P = *reinterpret_cast<const uint4*>(abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));                 \
   } else {                                                                                                                \
     const unsigned rl_ = min(64u * ((J) - kWL) + cm_lane, lrmax);                                                         \
-    P = *reinterpret_cast<const uint4*>(abase + ((rl_ >> 7) * astride + (rl_ & 127u) * 16u + cm_chunk));                  \
+    P = *reinterpret_cast<const uint4*>(abase + dl::cm_src_offset(rl_, cm_chunk, astride));                               \
   }
 #define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
 // LDS image of a slab (both layouts): row r (weights 0 .. FP-1, rays FP ..) at r * kPRow: [plane h 64 B | plane l 64 B].  DST = the stage's
@@ -339,7 +337,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
       const bool planes_out = A.out_f32 == nullptr;
       {
         // lane_e: rays rayl_e + 32 tn, features (of the pass) tm*128 + wm_e*32 + 8*(r>>2) + 4*(lane_e>>5) + (r&3) -- with permuted weight rows
-        // (OUTCM) tm*128 + wm_e*32 + dense_row_perm(the same) = .. + 16*(r>>3) + 8*(lane_e>>5) + 4*((r>>2)&1) + (r&3); acc becomes the layer output in
+        // (OUTCM) tm*128 + wm_e*32 + dl::row_perm(the same) = .. + 16*(r>>3) + 8*(lane_e>>5) + 4*((r>>2)&1) + (r&3); acc becomes the layer output in
         // place.  All factors are powers of two (exact): value = fma(acc * 2^-shift_in, 1 / weight-row scale, bias), one rounding.  Packed
         // fp32 multiplies / fmas, the ReLU as a maximum with 0 or -inf, the row maximum as max3: 2.5 VALU operations per value.
         const int glast = (ks - 1) >> 2;
@@ -354,7 +352,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           for (int tn = 0; tn < NTN; ++tn) rmax[tn] = 0.f;
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int fl4 = f0 + tm * 128 + wm_e * 32 + (OUTCM ? 16 * (rg >> 1) + 8 * (lane_e >> 5) + 4 * (rg & 1) : 8 * rg + 4 * (lane_e >> 5));
+            const int fl4 = f0 + tm * 128 + wm_e * 32 + dl::acc_feature(OUTCM, lane_e, 4 * rg);      // registers 4 rg .. 4 rg + 3: 4 consecutive features
             const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + kMaxN + fl4);
             const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
             const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
@@ -466,7 +464,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
           for (int tn = 0; tn < NTN; ++tn) {
             const int64_t gr = ray0 + rayl_e + 32 * tn;
             if (gr < A.m) {
-              char* const ob = A.out_planes + ((gr >> 7) * nslab_out + ((f0 >> 5) + tm * 4 + wm_e)) * (int64_t)kGranSlab + (lane_e >> 5) * kChunkRun + (gr & 127) * 16;
+              char* const ob = A.out_planes + dl::cm_offset(gr, nslab_out, (f0 >> 5) + tm * 4 + wm_e, 0, lane_e >> 5);      // chunk 2 pp + h: + 2 pp runs
 #pragma unroll
               for (int pp = 0; pp < 2; ++pp) {
                 *reinterpret_cast<float4*>(ob + (2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp], acc[tm][tn][8 * pp + 1], acc[tm][tn][8 * pp + 4], acc[tm][tn][8 * pp + 5]};
@@ -618,8 +616,7 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
       l[e] = (_Float16)(x - (float)hh);
     }
     const int64_t gr = ray0 + r;
-    char* const dst = chunk_major ? xp + ((gr >> 7) * 5 + (g8 >> 2)) * kGranSlab + (g8 & 3) * kChunkRun + (gr & 127) * 16
-                                  : xp + (gr * 5 + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
+    char* const dst = xp + (chunk_major ? dl::cm_offset(gr, 5, g8 >> 2, 0, g8 & 3) : dl::rm_offset(gr, 5, g8 >> 2, 0, g8 & 3));
     *reinterpret_cast<f16x8_t*>(dst) = h;
     *reinterpret_cast<f16x8_t*>(dst + (chunk_major ? 4 * kChunkRun : 64)) = l;
     if (g8 == 0) { xs[2 * (ray0 + r)] = sh; xs[2 * (ray0 + r) + 1] = sh; }
@@ -627,13 +624,13 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
 }
 
 // weights fp32 [n][ld] (columns c0 .. c0 + kcols of every row; zero beyond) -> planes [n][ks_total][128 B] at slab offset s_off, scaled by
-// the row's power of two f3_scale(wmax[row]); perm: plane row (row & ~31) + m holds feature (row & ~31) + dense_row_perm(m)
+// the row's power of two f3_scale(wmax[row]); perm: plane row (row & ~31) + m holds feature (row & ~31) + dl::row_perm(m)
 __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__ src, int n, int64_t ld, int c0, int kcols, int kslabs, const float* __restrict__ wmax,
                                                        char* __restrict__ dst, int ks_total, int s_off, int perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (plane row, group of 8 columns)
   if (i >= n * kslabs * 4) return;
   const int prow = i / (kslabs * 4), g8 = i - prow * (kslabs * 4);
-  const int row = perm ? (prow & ~31) | dense_row_perm(prow & 31) : prow;
+  const int row = perm ? (prow & ~31) | dl::row_perm(prow & 31) : prow;
   const float sc = f3_scale(wmax[row]);
   f16x8_t h, l;
 #pragma unroll

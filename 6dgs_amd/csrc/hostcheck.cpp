@@ -1,9 +1,11 @@
-// hostcheck.cpp -- HOST instantiation of device_math.h (the per-thread math of the HIP kernels) behind
+// hostcheck.cpp -- HOST instantiation of device_math.h (the per-thread math of the HIP kernels) and of dense_layout.h (the index
+// arithmetic of the ray-MLP chain's operand planes) behind
 // a tiny C ABI, so the CPU test-suite can compare the product's arithmetic with the oracle and the
 // golden vectors without a GPU.  Contains no kernels; never used by the product path.
 #include <stdlib.h>
 
 #include "device_math.h"
+#include "dense_layout.h"
 using namespace sdg;
 
 extern "C" {
@@ -118,6 +120,25 @@ void hc_pose_errors(const float* gt, const float* pr, float* out2) { pose_errors
 void hc_distance_target(const float* pose, const float* ori, const float* dir, long long r, float* out) {
   for (long long i = 0; i < r; ++i)
     out[i] = distance_target(pose, v3(ori[3 * i], ori[3 * i + 1], ori[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+}
+
+// ---- dense_layout.h: the ray-MLP chain's operand planes (tests/test_dense_layout.py walks a tag through them) ----
+int hc_dl_row_perm(int m) { return dl::row_perm(m); }
+int hc_dl_acc_row(int lane, int r) { return dl::acc_row(lane, r); }
+int hc_dl_acc_feature(int permuted, int lane, int r) { return dl::acc_feature(permuted != 0, lane, r); }
+long long hc_dl_plane_offset(int chunk_major, long long ray, int nslab, int slab, int plane, int c) {
+  return chunk_major ? dl::cm_offset(ray, nslab, slab, plane, c) : dl::rm_offset(ray, nslab, slab, plane, c);
+}
+unsigned hc_dl_lds_offset(unsigned row, unsigned plane, unsigned c) { return dl::lds_offset(row, plane, c); }
+unsigned hc_dl_frag_offset(unsigned row0, unsigned lane, unsigned ks, unsigned plane) { return dl::frag_offset(row0, lane, ks, plane); }
+unsigned hc_dl_load_ray(int chunk_major, unsigned tid, unsigned jp) { return dl::load_ray(chunk_major != 0, tid, jp); }
+unsigned hc_dl_load_chunk8(int chunk_major, unsigned tid) { return dl::load_chunk8(chunk_major != 0, tid); }
+unsigned hc_dl_cm_src_offset(unsigned ray_in_tile, unsigned chunk8, unsigned granule_stride) {
+  return dl::cm_src_offset(ray_in_tile, chunk8 * (unsigned)dl::kChunkRun, granule_stride);
+}
+int hc_dl_const(int which) {
+  const int v[] = {dl::kSlabB, dl::kPRow, dl::kGran, dl::kGranSlab, dl::kChunkRun};
+  return which >= 0 && which < 5 ? v[which] : -1;
 }
 
 }  // extern "C"
