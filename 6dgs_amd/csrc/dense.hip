@@ -766,21 +766,27 @@ __global__ void __launch_bounds__(512, 1) k_dense_dma(DenseArgs A, unsigned n_pa
       const unsigned sw = ring0 + uw * (unsigned)kWUnit + fa0;
       const unsigned sr = ring0 + (unsigned)(WU * kWUnit) + ur * (unsigned)kRUnit + fb0;
       f16x8_t a[NTM][2], b[NTN][2];
+      // the first term (l*h) needs the weights' plane l and the rays' plane h: those fragments are read first and waited for alone (LDS reads return in
+      // order), the other half arrives under the first NTM NTN MFMAs
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
+      for (int t = 0; t < NTM; ++t) a[t][1] = dma_read_b128(sw, 1 * (2 * FP * 16) + t * 128 * 16);
 #pragma unroll
-        for (int t = 0; t < NTM; ++t) a[t][pl] = dma_read_b128(sw, pl * (2 * FP * 16) + t * 128 * 16);
+      for (int t = 0; t < NTN; ++t) b[t][0] = dma_read_b128(sr, 0 * (2 * RT * 16) + t * 32 * 16);
 #pragma unroll
-        for (int t = 0; t < NTN; ++t) b[t][pl] = dma_read_b128(sr, pl * (2 * RT * 16) + t * 32 * 16);
-      }
-      dma_wait_lds();      // the unit is in registers: behind the next barrier its slot may be overwritten
+      for (int t = 0; t < NTM; ++t) a[t][0] = dma_read_b128(sw, 0 * (2 * FP * 16) + t * 128 * 16);
+#pragma unroll
+      for (int t = 0; t < NTN; ++t) b[t][1] = dma_read_b128(sr, 1 * (2 * RT * 16) + t * 32 * 16);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NTM + NTN) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qq = 0; qq < 3; ++qq) {                        // (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first
         const int pa = qq == 0 ? 1 : 0, pb = qq == 1 ? 1 : 0;
+        if (qq == 1) dma_wait_lds();                          // the unit is in registers: behind the next barrier its slot may be overwritten
 #pragma unroll
         for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], b[tn][pb], acc[tm][tn], 0, 0, 0);
+        if (qq == 0) __builtin_amdgcn_sched_barrier(0);       // (the first term's MFMAs stay in front of the second wait)
       }
     }
     if (++uw == (unsigned)WU) uw = 0;
