@@ -14,3 +14,11 @@ if grep -q "CM_CHECK PASS" $O/compare.log; then
   SIXDGS_DENSE_DMA=1 bash tools/trace_keys.sh dma_ab/trace > /dev/null 2>&1
   grep layer gpurun_out/dma_ab/trace/layers.txt
 fi
+# 4. the default kernels with the fragment reads in first-term order (private build made beforehand: python tools/build_variant.py frag -DSDG_FRAG_ORDER=1)
+if [ -f build/variants/lib_frag.so ]; then
+  for i in 1 2; do
+    timeout 60 python tools/time_keys.py 8388608 2>&1 | grep "planes only" | sed 's/^/default    /' >> $O/frag.log
+    SIXDGS_LIB=$PWD/build/variants/lib_frag.so timeout 60 python tools/time_keys.py 8388608 2>&1 | grep "planes only" | sed 's/^/frag-order /' >> $O/frag.log
+  done
+  cat $O/frag.log
+fi
