@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
       f16x8_t a[NTM][2], b[NTN][2];
 #pragma unroll
       for (int kstep = 0; kstep < 2; ++kstep) {
-#if SDG_FRAG_ORDER      // (round-4 A/B, tools/dma_ab.sh: the planes the first term l*h needs first, so that its MFMAs can start under the other reads)
+#if SDG_FRAG_ORDER      // (round-4 A/B, profiles/r04_chain_lds_dma_ab.log: the planes the first term l*h needs first -- 305.9 / 304.8 vs 301.9 / 305.7 TFLOP/s: no difference; not the default)
 #pragma unroll
         for (int t = 0; t < NTM; ++t) a[t][1] = *reinterpret_cast<const f16x8_t*>(sw + t * 128 * kPRow + 64 + kstep * 32);
 #pragma unroll
@@ -576,360 +576,6 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------------
-// k_dense_dma -- the same layer (chunk-major planes in and out, permuted weight rows) with the operands going HBM / L2 -> LDS by LDS-DMA
-// (global_load_lds), no staging registers and no ds_write.  EXPERIMENTAL, opt-in (SIXDGS_DENSE_DMA=1, with the chunk-major layout): written at
-// the end of round 3 without GPU time left to run it; tools/cm_check.py is its first test (it must reproduce the keys bit for bit: same MFMA
-// order per output, same epilogue arithmetic).
-//   ring unit = one K-STEP (16 inputs) of an operand, dense_layout.h: weights [plane 2][chunk 2][FP rows][16 B], rays [..][RT rays][16 B];
-//   weights WU = 4 units (from L2), rays RU = 5 / 6 units (from HBM): 144 KB, beside 12 / 8.6 KB of tables.  Weight planes chunk-major
-//   [slab][plane][chunk][row][16 B] (packed once), so a DMA piece -- 64 consecutive rows of one (plane, chunk) -- is 1 KB of consecutive
-//   bytes on both sides; nothing is swizzled: a fragment read is two runs of 512 consecutive bytes.
-//   k-step j:  s_waitcnt vmcnt(kWait)  -- this wave's pieces of unit j have landed (in-order completion; kWait = the pieces issued since)
-//              s_barrier               -- everybody's have, and everybody has read unit j - 1 into registers
-//              issue weights unit j + WU - 1 and rays unit j + RU - 1 into the slots of unit j - 1
-//              fragments of unit j -> registers, lgkmcnt(0), 6 NTM NTN MFMAs
-//   Stores and the shift loads between the DMA pieces only make the counted wait stricter (they are younger than what is waited for).
-// LDS reads of k_dense_dma's k-step loop as inline assembly: behind an LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of every LDS access it
-// emits itself (the DMA writes LDS), which would drain the ring at every k-step; the waits are counted by hand instead (as in score.hip).
-__device__ __forceinline__ f16x8_t dma_read_b128(unsigned addr, const int imm) {
-  f16x8_t v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
-  return v;
-}
-__device__ __forceinline__ int dma_read_b32(unsigned addr, const int imm) {
-  int v;
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
-  return v;
-}
-__device__ __forceinline__ void dma_wait_lds() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int NTM, int NTN>
-__global__ void __launch_bounds__(512, 1) k_dense_dma(DenseArgs A, unsigned n_pass, unsigned total_tiles, unsigned split) {
-  constexpr int FP = 128 * NTM, RT = 64 * NTN;
-  constexpr int WU = 4, RU = NTN == 4 ? 5 : 6;
-  constexpr int kWUnit = FP * 64, kRUnit = RT * 64;          // bytes of a ring unit
-  constexpr int kWP = FP / 128, kRP = RT / 128;              // DMA pieces per wave and k-step
-  constexpr int kWait = (WU - 2) * (kWP + kRP) + kRP;        // pieces a wave has issued after the weights of the unit it is about to use
-  constexpr int kNS = (kMaxGroups * RT + 511) / 512;
-  static_assert(RT >= 128 && kRP >= 1, "a ray unit is at least one piece per wave");
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-  __shared__ __attribute__((aligned(1024))) char ring[WU * kWUnit + RU * kRUnit];
-  __shared__ unsigned wmaxb[NTM][RT];
-  __shared__ __attribute__((aligned(16))) float cwb[2 * kMaxN];
-  __shared__ int shl[kMaxGroups][RT];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ks = A.ks0 + A.ks1;
-  const int nb_all = A.n >> 7;
-  f32x16 acc[NTM][NTN];
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned pbase = split ? (w & 1u) : 0u;
-  const unsigned npl = split ? 1u : n_pass;
-  const unsigned tstride = split ? gridDim.x >> 1 : gridDim.x;
-  unsigned tile = split ? w >> 1 : w;
-  int64_t ray0 = (int64_t)tile * RT;
-
-  // the input shifts of a tile's rays go into the table [group][ray] by LDS-DMA as well (4 bytes per lane, 64 consecutive rays of one group per
-  // piece): no registers, and ordered with the ring's pieces by the same counted waits.  Issued when the table's previous contents have been
-  // read for the last time (at the start of the tile's last epilogue), first needed four slabs later.
-#define SDG_SHIFT_DMA(R0)                                                                                                  \
-  _Pragma("unroll") for (int k_ = 0; k_ < kNS; ++k_) {                                                                     \
-    const int i0_ = 64 * wave + 512 * k_;                                                                                  \
-    if (i0_ < (A.g0 + A.g1) * RT) {                                                                                        \
-      const int g_ = i0_ / RT;                                                                                             \
-      const int64_t cray_ = min((R0) + (i0_ % RT) + lane, A.m - 1);                                                        \
-      const int* src_ = g_ < A.g0 ? A.s0 + cray_ * A.g0 + g_ : A.s1 + cray_ * A.g1 + (g_ - A.g0);                          \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src_, (lds_ptr_t)(&shl[0][0] + i0_), 4, 0, 0);                           \
-    }                                                                                                                      \
-  }
-  for (int i = tid; i < A.n; i += 512) {
-    cwb[i] = f3_inv_scale(A.wmax[i]);
-    cwb[kMaxN + i] = A.bias[i];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the table writes first: an LDS access behind a DMA in flight waits for it)
-  SDG_SHIFT_DMA(ray0)
-
-  // ---- DMA pieces of this wave: piece q = wave + 8 i of a unit (dense_layout.h) --------------------------------------------------------
-  unsigned w_src[kWP], r_ray[kRP];      // per lane: source byte offset of the weights piece within its (slab, k-step); ray (within the tile) of the ray piece
-  int w_dst[kWP], r_dst[kRP], r_run[kRP];
-#pragma unroll
-  for (int i = 0; i < kWP; ++i) {
-    const int q = wave + 8 * i, run = dl::piece_run(FP, q), row0 = dl::piece_row0(FP, q);
-    w_src[i] = (unsigned)dl::wcm_offset(A.n, 0, run >> 1, run & 1, row0 + lane);      // + (slab 8 + 2 k-step) n 16 + first row of the pass x 16
-    w_dst[i] = q * 1024;
-  }
-#pragma unroll
-  for (int i = 0; i < kRP; ++i) {
-    const int q = wave + 8 * i, run = dl::piece_run(RT, q);
-    r_ray[i] = (unsigned)(dl::piece_row0(RT, q) + lane);
-    r_run[i] = (run >> 1) * 4 * kChunkRun + (run & 1) * kChunkRun;                     // (plane, chunk-of-the-k-step) within a (granule, slab)
-    r_dst[i] = WU * kWUnit + q * 1024;
-  }
-  // load cursors (wave-uniform): weights (pass, slab, k-step) cycle per tile; rays (tile, pass, slab, k-step), staying on the last pass at the end
-  unsigned cw_b = 0, cw_s = 0, cw_k = 0, wslot = 0;
-  unsigned cr_t = tile, cr_b = 0, cr_s = 0, cr_k = 0, rslot = 0;
-  const char *cr_ab0, *cr_ab1;
-  unsigned cr_lrmax;
-#define SDG_RAYBASE()                                                                                                     \
-  {                                                                                                                       \
-    const int64_t r0_ = (int64_t)cr_t * RT;                                                                               \
-    cr_ab0 = A.a0 + (r0_ >> 7) * A.ks0 * kGranSlab;                                                                       \
-    cr_ab1 = A.a1 ? A.a1 + (r0_ >> 7) * A.ks1 * kGranSlab : cr_ab0;                                                       \
-    cr_lrmax = (unsigned)min((int64_t)(RT - 1), A.m - 1 - r0_);                                                           \
-  }
-  SDG_RAYBASE()
-#define SDG_ISSUE_W()                                                                                                     \
-  {                                                                                                                       \
-    const char* b_ = A.wp + (((int64_t)(cw_s * 8u + 2u * cw_k) * A.n + (int64_t)(pbase + cw_b) * FP) * 16);              \
-    _Pragma("unroll") for (int i_ = 0; i_ < kWP; ++i_)                                                                    \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_ + w_src[i_]), (lds_ptr_t)(ring + wslot * kWUnit + w_dst[i_]), 16, 0, 0); \
-    if (++cw_k == 2u) {                                                                                                   \
-      cw_k = 0;                                                                                                           \
-      if (++cw_s == (unsigned)ks) {                                                                                       \
-        cw_s = 0;                                                                                                         \
-        if (++cw_b == npl) cw_b = 0;                                                                                      \
-      }                                                                                                                   \
-    }                                                                                                                     \
-    if (++wslot == (unsigned)WU) wslot = 0;                                                                               \
-  }
-#define SDG_ISSUE_R()                                                                                                     \
-  {                                                                                                                       \
-    const bool seg1_ = cr_s >= (unsigned)A.ks0;                                                                           \
-    const unsigned gstr_ = (unsigned)(seg1_ ? A.ks1 : A.ks0) * (unsigned)kGranSlab;                                       \
-    const char* b_ = (seg1_ ? cr_ab1 + (cr_s - (unsigned)A.ks0) * (unsigned)kGranSlab : cr_ab0 + cr_s * (unsigned)kGranSlab) + cr_k * (2u * kChunkRun); \
-    _Pragma("unroll") for (int i_ = 0; i_ < kRP; ++i_) {                                                                  \
-      const unsigned rl_ = min(r_ray[i_], cr_lrmax);                                                                      \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_ + dl::cm_src_offset(rl_, (unsigned)r_run[i_], gstr_)),              \
-                                       (lds_ptr_t)(ring + rslot * kRUnit + r_dst[i_]), 16, 0, 0);                         \
-    }                                                                                                                     \
-    if (++cr_k == 2u) {                                                                                                   \
-      cr_k = 0;                                                                                                           \
-      if (++cr_s == (unsigned)ks) {                                                                                       \
-        cr_s = 0;                                                                                                         \
-        if (++cr_b == npl) {                                                                                              \
-          if (cr_t + tstride < total_tiles) {                                                                             \
-            cr_b = 0;                                                                                                     \
-            cr_t += tstride;                                                                                              \
-            SDG_RAYBASE()                                                                                                 \
-          } else {                                                                                                        \
-            cr_b = npl - 1;                                                                                               \
-          }                                                                                                               \
-        }                                                                                                                 \
-      }                                                                                                                   \
-    }                                                                                                                     \
-    if (++rslot == (unsigned)RU) rslot = 0;                                                                               \
-  }
-  // prologue in the steady-state order: the rays' extra lead first, then (weights u, rays u + RU - WU) as k-steps -(WU-1) .. -1 would have issued them
-#pragma unroll
-  for (int u = 0; u < RU - WU; ++u) SDG_ISSUE_R()
-#pragma unroll
-  for (int u = 0; u < WU - 1; ++u) {
-    SDG_ISSUE_W()
-    SDG_ISSUE_R()
-  }
-#pragma unroll
-  for (int i = 0; i < NTM; ++i)
-#pragma unroll
-    for (int j = 0; j < NTN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // fragment bases of this lane within a unit (run = plane 2 + (lane >> 5); the plane adds 2 rows-of-the-unit x 16 B, a row block 512 B)
-  const unsigned fa0 = dl::unit_frag_offset(FP, wm * 32, lane, 0), fb0 = dl::unit_frag_offset(RT, wn * 32 * NTN, lane, 0);
-  const unsigned ring0 = (unsigned)(uintptr_t)(lds_ptr_t)ring, shl0 = (unsigned)(uintptr_t)(lds_ptr_t)&shl[0][0];
-  int s = 0, kk = 0;                 // slab and k-step of the pass
-  unsigned uw = 0, ur = 0;           // ring slots of the unit in use
-  unsigned pass = 0;
-  int since_epi = WU - 1;            // k-steps since the last epilogue, saturating at WU - 1 (the prologue's units are waited for)
-  while (true) {                     // one k-step; flattened over (tile, pass, slab, k-step)
-    // (the first WU - 1 k-steps behind an epilogue use units that landed before it -- the epilogue starts with vmcnt(0) and a barrier -- so they
-    // do not wait: the counted wait would also cover the epilogue's stores, which are younger than those units but older than the next pieces)
-    if (since_epi >= WU - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWait) : "memory");
-    else ++since_epi;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    SDG_ISSUE_W()
-    SDG_ISSUE_R()
-    if (kk == 0) {
-      if ((s & 3) == 0 && s > 0) {         // a new 128-input block: accumulators to its scale (exact powers of two)
-        unsigned t_ = threadIdx.x;
-        asm volatile("" : "+v"(t_));
-        const unsigned sp = shl0 + (unsigned)(((s >> 2) * RT + ((t_ >> 6) & 1) * 32 * NTN + (t_ & 31)) * 4);
-        int cur[NTN], prv[NTN];
-#pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) {
-          cur[tn] = dma_read_b32(sp, 32 * tn * 4);
-          prv[tn] = dma_read_b32(sp - RT * 4, 32 * tn * 4);
-        }
-        dma_wait_lds();
-#pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) {
-          const float fac = pow2i(cur[tn] - prv[tn]);
-#pragma unroll
-          for (int tm = 0; tm < NTM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= fac;
-        }
-      }
-    }
-    {
-      const unsigned sw = ring0 + uw * (unsigned)kWUnit + fa0;
-      const unsigned sr = ring0 + (unsigned)(WU * kWUnit) + ur * (unsigned)kRUnit + fb0;
-      f16x8_t a[NTM][2], b[NTN][2];
-      // the first term (l*h) needs the weights' plane l and the rays' plane h: those fragments are read first and waited for alone (LDS reads return in
-      // order), the other half arrives under the first NTM NTN MFMAs
-#pragma unroll
-      for (int t = 0; t < NTM; ++t) a[t][1] = dma_read_b128(sw, 1 * (2 * FP * 16) + t * 128 * 16);
-#pragma unroll
-      for (int t = 0; t < NTN; ++t) b[t][0] = dma_read_b128(sr, 0 * (2 * RT * 16) + t * 32 * 16);
-#pragma unroll
-      for (int t = 0; t < NTM; ++t) a[t][0] = dma_read_b128(sw, 0 * (2 * FP * 16) + t * 128 * 16);
-#pragma unroll
-      for (int t = 0; t < NTN; ++t) b[t][1] = dma_read_b128(sr, 1 * (2 * RT * 16) + t * 32 * 16);
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NTM + NTN) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int qq = 0; qq < 3; ++qq) {                        // (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first
-        const int pa = qq == 0 ? 1 : 0, pb = qq == 1 ? 1 : 0;
-        if (qq == 1) dma_wait_lds();                          // the unit is in registers: behind the next barrier its slot may be overwritten
-#pragma unroll
-        for (int tm = 0; tm < NTM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < NTN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], b[tn][pb], acc[tm][tn], 0, 0, 0);
-        if (qq == 0) __builtin_amdgcn_sched_barrier(0);       // (the first term's MFMAs stay in front of the second wait)
-      }
-    }
-    if (++uw == (unsigned)WU) uw = 0;
-    if (++ur == (unsigned)RU) ur = 0;
-    if (++kk == 2) {
-      kk = 0;
-      ++s;
-    }
-    if (s == ks) {      // the pass is complete
-      unsigned te = threadIdx.x;
-      asm volatile("" : "+v"(te));
-      const int lane_e = (int)(te & 63u), wave_e = __builtin_amdgcn_readfirstlane((int)(te >> 6));
-      const int wm_e = wave_e >> 1, wn_e = wave_e & 1;
-      const int rayl_e = wn_e * 32 * NTN + (lane_e & 31);
-      // every piece in flight has landed once all waves are past this wait and the barrier below: the epilogue's own LDS accesses (tables) would
-      // make the compiler drain the DMA anyway; said here, the k-steps behind the epilogue can rely on it
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      since_epi = 0;
-      const int glast = (ks - 1) >> 2;
-      float ib[NTN];      // 2^-shift of the last input block: the table's last use for this pass
-#pragma unroll
-      for (int tn = 0; tn < NTN; ++tn) ib[tn] = pow2i(-shl[glast][rayl_e + 32 * tn]);
-      for (int i = te; i < NTM * RT; i += 512) (&wmaxb[0][0])[i] = 0u;
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const bool tile_done = pass + 1 == npl;
-      const unsigned next_tile = tile_done ? tile + tstride : tile;
-      const int f0 = (int)(pbase + pass) * FP;
-      typedef float f32x2_t __attribute__((ext_vector_type(2)));
-      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-      {
-        const float relu_floor = A.relu ? 0.f : -__builtin_inff();
-#pragma unroll
-        for (int tm = 0; tm < NTM; ++tm) {
-          float rmax[NTN];
-#pragma unroll
-          for (int tn = 0; tn < NTN; ++tn) rmax[tn] = 0.f;
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int fl4 = f0 + tm * 128 + wm_e * 32 + dl::acc_feature(true, lane_e, 4 * rg);
-            const float4 iw4 = *reinterpret_cast<const float4*>(cwb + fl4), b4 = *reinterpret_cast<const float4*>(cwb + kMaxN + fl4);
-            const f32x2_t iw[2] = {{iw4.x, iw4.y}, {iw4.z, iw4.w}};
-            const f32x2_t bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
-#pragma unroll
-            for (int tn = 0; tn < NTN; ++tn)
-#pragma unroll
-              for (int jp = 0; jp < 2; ++jp) {
-                f32x2_t v = {acc[tm][tn][4 * rg + 2 * jp], acc[tm][tn][4 * rg + 2 * jp + 1]};
-                v = v * f32x2_t{ib[tn], ib[tn]};
-                v = __builtin_elementwise_fma(v, iw[jp], bb[jp]);
-                const float x0 = fmaxf(v.x, relu_floor), x1 = fmaxf(v.y, relu_floor);
-                acc[tm][tn][4 * rg + 2 * jp] = x0;
-                acc[tm][tn][4 * rg + 2 * jp + 1] = x1;
-                rmax[tn] = fmaxf(fmaxf(rmax[tn], fabsf(x0)), fabsf(x1));
-              }
-          }
-#pragma unroll
-          for (int tn = 0; tn < NTN; ++tn) {
-            const float r2 = fmaxf(rmax[tn], __shfl_xor(rmax[tn], 32, 64));
-            if (lane_e < 32) atomicMax(&wmaxb[tm][rayl_e + 32 * tn], __float_as_uint(r2));
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const int nslab_out = A.n >> 5;
-      int shv[NTM][NTN];      // all block shifts first: an LDS read between the stores would wait for the stores issued before it
-#pragma unroll
-      for (int tm = 0; tm < NTM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) shv[tm][tn] = p_shift(__uint_as_float(wmaxb[tm][rayl_e + 32 * tn]));
-      // Nobody reads this tile's shifts any more (the last reads sit in front of the epilogue's first barrier) and the epilogue touches no table
-      // from here on (an LDS access behind a DMA in flight makes the compiler wait for it): the next tile's shifts are sent for.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (tile_done && next_tile < total_tiles) { SDG_SHIFT_DMA((int64_t)next_tile * RT) }
-#pragma unroll
-      for (int tm = 0; tm < NTM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < NTN; ++tn) {
-          const int ray = rayl_e + 32 * tn;
-          const int sh = shv[tm][tn];
-          const int64_t gr = ray0 + ray;
-          if (wm_e == 0 && lane_e < 32 && gr < A.m) A.out_shift[gr * nb_all + (f0 >> 7) + tm] = sh;
-          const float sc = pow2i(sh);
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            f16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float x = acc[tm][tn][4 * rg + j] * sc;
-              const _Float16 hh = (_Float16)x;
-              h[j] = hh;
-              l[j] = (_Float16)(x - (float)hh);
-            }
-            const f32x2_t hb = __builtin_bit_cast(f32x2_t, h), lb2 = __builtin_bit_cast(f32x2_t, l);
-            acc[tm][tn][4 * rg] = hb.x;
-            acc[tm][tn][4 * rg + 1] = hb.y;
-            acc[tm][tn][4 * rg + 2] = lb2.x;
-            acc[tm][tn][4 * rg + 3] = lb2.y;
-          }
-          if (gr < A.m) {
-            char* const ob = A.out_planes + dl::cm_offset(gr, nslab_out, (f0 >> 5) + tm * 4 + wm_e, 0, lane_e >> 5);
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-              *reinterpret_cast<float4*>(ob + (2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp], acc[tm][tn][8 * pp + 1], acc[tm][tn][8 * pp + 4], acc[tm][tn][8 * pp + 5]};
-              *reinterpret_cast<float4*>(ob + (4 + 2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp + 2], acc[tm][tn][8 * pp + 3], acc[tm][tn][8 * pp + 6], acc[tm][tn][8 * pp + 7]};
-            }
-          }
-        }
-      if (++pass == npl) {      // next tile of this workgroup
-        pass = 0;
-        tile = next_tile;
-        if (tile >= total_tiles) break;
-        ray0 = (int64_t)tile * RT;
-      }
-#pragma unroll
-      for (int i_ = 0; i_ < NTM; ++i_)
-#pragma unroll
-        for (int j_ = 0; j_ < NTN; ++j_)
-#pragma unroll
-          for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;
-      s = 0;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing prefetches must have landed before the workgroup's LDS is handed on
-#undef SDG_ISSUE_W
-#undef SDG_ISSUE_R
-#undef SDG_RAYBASE
-#undef SDG_SHIFT_DMA
-}
-
 // a12 as planes: x[R][5 slabs][2 planes][32] (141 inputs, zero padded to 160), one shift per ray from the bound max(1, |coordinates|).
 // One workgroup = 64 rays.  The 66 (component, frequency) arguments of a ray give sine AND cosine with one argument reduction (sincosf:
 // the thread-per-8-inputs form this replaces called sinf / cosf 132 times per ray, each with its own reduction -- coordinates times 2^7
@@ -994,7 +640,7 @@ __global__ void __launch_bounds__(256) k_ray_encode_planes(const float* __restri
 // weights fp32 [n][ld] (columns c0 .. c0 + kcols of every row; zero beyond) -> planes [n][ks_total][128 B] at slab offset s_off, scaled by
 // the row's power of two f3_scale(wmax[row]); perm: plane row (row & ~31) + m holds feature (row & ~31) + dl::row_perm(m)
 __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__ src, int n, int64_t ld, int c0, int kcols, int kslabs, const float* __restrict__ wmax,
-                                                       char* __restrict__ dst, int ks_total, int s_off, int perm, int chunk_major) {
+                                                       char* __restrict__ dst, int ks_total, int s_off, int perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (plane row, group of 8 columns)
   if (i >= n * kslabs * 4) return;
   const int prow = i / (kslabs * 4), g8 = i - prow * (kslabs * 4);
@@ -1009,11 +655,6 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
     h[e] = hh;
     l[e] = (_Float16)(x - (float)hh);
   }
-  if (chunk_major) {      // [slab][plane][chunk][row n][16 B] (k_dense_dma)
-    *reinterpret_cast<f16x8_t*>(dst + dl::wcm_offset(n, s_off + (g8 >> 2), 0, g8 & 3, prow)) = h;
-    *reinterpret_cast<f16x8_t*>(dst + dl::wcm_offset(n, s_off + (g8 >> 2), 1, g8 & 3, prow)) = l;
-    return;
-  }
   char* d = dst + ((int64_t)prow * ks_total + s_off + (g8 >> 2)) * kSlabB + (g8 & 3) * 16;
   *reinterpret_cast<f16x8_t*>(d) = h;
   *reinterpret_cast<f16x8_t*>(d + 64) = l;
@@ -1025,15 +666,8 @@ bool g_dense_no_split = getenv("SIXDGS_DENSE_NO_SPLIT") != nullptr;      // deve
 // same keys bit for bit (same MFMA order per output, same scales; tools/cm_check.py, test_chain_layouts_give_identical_keys); chunk-major is
 // 3-4 % faster (290 -> 302 TFLOP/s fp32-equivalent, 8 M rays, alternating runs on one box; profiles/r03_chain_chunk_major.log).
 constexpr bool kChunkMajorDefault = true;
-// SIXDGS_DENSE_DMA=1 (with the chunk-major layout): layers 1-4 run k_dense_dma, their weight planes are packed chunk-major.  Experimental, off.
-bool dense_dma();
 bool dense_chunk_major() {
   static const bool on = [] { const char* e = getenv("SIXDGS_DENSE_CM"); return e ? atoi(e) != 0 : kChunkMajorDefault; }();
-  return on;
-}
-
-bool dense_dma() {
-  static const bool on = [] { const char* e = getenv("SIXDGS_DENSE_DMA"); return e && atoi(e) != 0 && dense_chunk_major(); }();
   return on;
 }
 
@@ -1066,14 +700,12 @@ int launch_dense(const DenseArgs& A, hipStream_t s) {
   const dim3 g((unsigned)grid), b(512);
   const unsigned nt = (unsigned)tiles;
   if (wide) {
-    if (A.cm_out && dense_dma()) hipLaunchKernelGGL((k_dense_dma<3, 2>), g, b, 0, s, A, n_pass, nt, 0u);
-    else if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<3, 2, true, true>), g, b, 0, s, A, n_pass, nt, 0u);
+    if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<3, 2, true, true>), g, b, 0, s, A, n_pass, nt, 0u);
     else if (A.cm_in) hipLaunchKernelGGL((k_dense_planes<3, 2, true, false>), g, b, 0, s, A, n_pass, nt, 0u);
     else hipLaunchKernelGGL((k_dense_planes<3, 2, false, false>), g, b, 0, s, A, n_pass, nt, 0u);
   } else {
     if (A.cm_in != A.cm_out) return SIXDGS_E_BADARG;      // (the N = 512 layers are inner layers)
-    if (A.cm_out && dense_dma()) hipLaunchKernelGGL((k_dense_dma<2, 4>), g, b, 0, s, A, n_pass, nt, split);
-    else if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<2, 4, true, true>), g, b, 0, s, A, n_pass, nt, split);
+    if (A.cm_out) hipLaunchKernelGGL((k_dense_planes<2, 4, true, true>), g, b, 0, s, A, n_pass, nt, split);
     else hipLaunchKernelGGL((k_dense_planes<2, 4, false, false>), g, b, 0, s, A, n_pass, nt, split);
   }
   SDG_LAUNCH_OK();
@@ -1105,7 +737,7 @@ int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipSt
   };
   for (const L& l : layers)
     hipLaunchKernelGGL(k_weight_planes, dim3((unsigned)sdg_cdiv((int64_t)l.n * l.kslabs * 4, 256)), dim3(256), 0, s, l.src, l.n, l.ld, l.c0, l.kcols, l.kslabs,
-                       l.wmax, planes + l.off, l.ks_total, l.s_off, l.perm, (l.perm && dense_dma()) ? 1 : 0);
+                       l.wmax, planes + l.off, l.ks_total, l.s_off, l.perm);
   SDG_LAUNCH_OK();
   return 0;
 }

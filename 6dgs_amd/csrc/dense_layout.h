@@ -50,20 +50,6 @@ SDG_DL unsigned cm_src_offset(unsigned ray_in_tile, unsigned chunk8_bytes, unsig
   return (ray_in_tile >> 7) * granule_stride + (ray_in_tile & 127u) * 16u + chunk8_bytes;
 }
 
-// ---- LDS-DMA form of the chain (k_dense_dma): the ring unit is a K-STEP (16 inputs) of an operand: 4 (plane, chunk) runs of `rows` rows x 16 B,
-// [plane 2][chunk-of-the-k-step 2][row][16 B].  A DMA instruction moves one PIECE = 64 consecutive rows of one run = 1 KB of consecutive bytes on
-// both sides (LDS image lane-linear), so nothing is swizzled and a fragment read is two runs of 512 consecutive bytes.
-// weights, chunk-major (packed once): [slab][plane 2][chunk 4][row n][16 B]
-SDG_DL int64_t wcm_offset(int n, int slab, int plane, int c, int row) { return ((int64_t)((slab * 2 + plane) * 4 + c) * n + row) * 16; }
-// piece q (0 .. rows / 16 - 1) of a unit: run q / (rows / 64) = plane * 2 + chunk-of-the-k-step, rows 64 (q % (rows / 64)) .. + 63; LDS offset q KB
-SDG_DL int piece_run(int rows, int q) { return q / (rows / 64); }
-SDG_DL int piece_row0(int rows, int q) { return 64 * (q % (rows / 64)); }
-// byte offset of (run, row) within a unit, and of lane l's operand fragment of the 32-row block at row0 for plane `plane`
-SDG_DL unsigned unit_offset(unsigned rows, unsigned run, unsigned row) { return (run * rows + row) * 16u; }
-SDG_DL unsigned unit_frag_offset(unsigned rows, unsigned row0, unsigned lane, unsigned plane) {
-  return unit_offset(rows, plane * 2u + (lane >> 5), row0 + (lane & 31u));
-}
-
 #undef SDG_DL
 }  // namespace dl
 }  // namespace sdg

@@ -136,11 +136,6 @@ unsigned hc_dl_load_chunk8(int chunk_major, unsigned tid) { return dl::load_chun
 unsigned hc_dl_cm_src_offset(unsigned ray_in_tile, unsigned chunk8, unsigned granule_stride) {
   return dl::cm_src_offset(ray_in_tile, chunk8 * (unsigned)dl::kChunkRun, granule_stride);
 }
-long long hc_dl_wcm_offset(int n, int slab, int plane, int c, int row) { return dl::wcm_offset(n, slab, plane, c, row); }
-int hc_dl_piece_run(int rows, int q) { return dl::piece_run(rows, q); }
-int hc_dl_piece_row0(int rows, int q) { return dl::piece_row0(rows, q); }
-unsigned hc_dl_unit_offset(unsigned rows, unsigned run, unsigned row) { return dl::unit_offset(rows, run, row); }
-unsigned hc_dl_unit_frag_offset(unsigned rows, unsigned row0, unsigned lane, unsigned plane) { return dl::unit_frag_offset(rows, row0, lane, plane); }
 int hc_dl_const(int which) {
   const int v[] = {dl::kSlabB, dl::kPRow, dl::kGran, dl::kGranSlab, dl::kChunkRun};
   return which >= 0 && which < 5 ? v[which] : -1;

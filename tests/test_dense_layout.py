@@ -111,72 +111,3 @@ def test_a_layers_output_arrives_in_the_next_layers_fragments(hc, cm, producer, 
                 assert hbm[off // 2] == (gr * n + feat) * 2 + pl
     for consumer in ((2, 4), (3, 2)):
         _consume(hc, cm, hbm, consumer[0], consumer[1], n, m_rays, slabs=(0, nslab // 2, nslab - 1))
-
-
-def test_lds_dma_units_feed_the_fragments(hc):
-    """k_dense_dma (experimental): a ring unit is one k-step of an operand, moved by pieces of 64 rows x 16 B that are consecutive bytes on both
-    sides.  Weights: chunk-major planes [slab][plane][chunk][row][16 B]; rays: the chunk-major activation planes.  Every piece of every wave
-    lands where the fragment reads of the 8 waves expect their inputs."""
-    hc.hc_dl_wcm_offset.restype = C.c_longlong
-    hc.hc_dl_unit_offset.restype = C.c_uint
-    hc.hc_dl_unit_frag_offset.restype = C.c_uint
-    run_b, gran_slab = hc.hc_dl_const(4), hc.hc_dl_const(3)
-    for ntm, ntn, n, ks, m_rays in ((2, 4, 512, 5, 300), (3, 2, 384, 16, 200)):
-        fp, rt = 128 * ntm, 64 * ntn
-        # weight planes as k_weight_planes packs them (chunk-major): one tag per 16-byte chunk
-        wplanes = {}
-        for slab in range(ks):
-            for pl in range(2):
-                for c in range(4):
-                    for row in range(n):
-                        wplanes[hc.hc_dl_wcm_offset(n, slab, pl, c, row)] = (row, slab, pl, c)
-        assert len(wplanes) == ks * 8 * n and max(wplanes) == (ks * 8 * n - 1) * 16
-        for pass_ in range(n // fp):
-            for slab in (0, ks - 1):
-                for kstep in range(2):
-                    unit = {}
-                    base = ((slab * 8 + 2 * kstep) * n + pass_ * fp) * 16                       # the kernel's uniform part of the source address
-                    for wave in range(8):
-                        for i in range(fp // 128):
-                            q = wave + 8 * i
-                            run, row0 = hc.hc_dl_piece_run(fp, q), hc.hc_dl_piece_row0(fp, q)
-                            for lane in range(64):
-                                src = base + hc.hc_dl_wcm_offset(n, 0, run >> 1, run & 1, row0 + lane)
-                                dst = q * 1024 + lane * 16                                     # LDS-DMA: lane-linear within the piece
-                                assert dst == hc.hc_dl_unit_offset(fp, run, row0 + lane) and dst not in unit
-                                unit[dst] = wplanes[src]
-                    assert len(unit) == fp * 4
-                    for wave in range(8):
-                        wm = wave >> 1
-                        for lane in range(64):
-                            for pl in range(2):
-                                for tm in range(ntm):
-                                    a = hc.hc_dl_unit_frag_offset(fp, wm * 32, lane, 0) + pl * (2 * fp * 16) + tm * 128 * 16     # as the kernel forms it
-                                    assert unit[a] == (pass_ * fp + tm * 128 + wm * 32 + (lane & 31), slab, pl, 2 * kstep + (lane >> 5))
-        # rays: chunk-major activation planes of ks slabs -> unit -> B fragments, ragged last tile
-        for tile in range((m_rays + rt - 1) // rt):
-            r0 = tile * rt
-            lrmax = min(rt - 1, m_rays - 1 - r0)
-            for slab in (0, ks - 1):
-                for kstep in range(2):
-                    unit = {}
-                    base = (r0 >> 7) * ks * gran_slab + slab * gran_slab + kstep * 2 * run_b
-                    for wave in range(8):
-                        for i in range(rt // 128):
-                            q = wave + 8 * i
-                            run = hc.hc_dl_piece_run(rt, q)
-                            r_run = (run >> 1) * 4 * run_b + (run & 1) * run_b
-                            for lane in range(64):
-                                rl = min(hc.hc_dl_piece_row0(rt, q) + lane, lrmax)
-                                src = base + hc.hc_dl_cm_src_offset(rl, 0, ks * gran_slab) + r_run
-                                assert src == hc.hc_dl_plane_offset(1, r0 + rl, ks, slab, run >> 1, 2 * kstep + (run & 1))
-                                unit[q * 1024 + lane * 16] = (r0 + rl, slab, run >> 1, 2 * kstep + (run & 1))
-                    assert len(unit) == rt * 4
-                    for wave in range(8):
-                        wn = wave & 1
-                        for lane in range(64):
-                            for pl in range(2):
-                                for tn in range(ntn):
-                                    b = hc.hc_dl_unit_frag_offset(rt, wn * 32 * ntn, lane, 0) + pl * (2 * rt * 16) + tn * 32 * 16
-                                    ray = r0 + min(wn * 32 * ntn + tn * 32 + (lane & 31), lrmax)
-                                    assert unit[b] == (ray, slab, pl, 2 * kstep + (lane >> 5))

@@ -2,7 +2,7 @@
 `compare <file>` checks bit-equality against a saved run of the other layout and prints where any difference sits.
 
     SIXDGS_DENSE_CM=0 python tools/cm_check.py save /tmp/cm0.pt; SIXDGS_DENSE_CM=1 python tools/cm_check.py compare /tmp/cm0.pt
-    python tools/cm_check.py save /tmp/d.pt; SIXDGS_DENSE_DMA=1 python tools/cm_check.py compare /tmp/d.pt      (the experimental LDS-DMA kernel)
+
 """
 import importlib, os, sys
 os.environ.setdefault("SIXDGS_RANDOM_BACKBONE", "1")
@@ -21,7 +21,7 @@ for R, chunk in ((128 * 301 + 77, 262144), (128 * 301 + 77, 128 * 90), (5, 26214
     _, _, (planes, inv) = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True, max_chunk=chunk, norm_out=norm)
     _, key, _ = ops.ray_keys(o, d, c, w, want_key=True, want_planes=True, max_chunk=chunk)
     out[f"{R}_{chunk}"] = dict(planes=planes.cpu(), inv=inv.cpu(), key=key.cpu(), norm=norm.cpu())
-mode = {"0": "ray-major", "1": "chunk-major"}.get(os.environ.get("SIXDGS_DENSE_CM", ""), "default (chunk-major)") + (" + LDS-DMA kernel" if os.environ.get("SIXDGS_DENSE_DMA") == "1" else "")
+mode = {"0": "ray-major", "1": "chunk-major"}.get(os.environ.get("SIXDGS_DENSE_CM", ""), "default (chunk-major)")
 if sys.argv[1] == "save":
     torch.save(out, sys.argv[2])
     print(f"saved {len(out)} cases, layout {mode}")
