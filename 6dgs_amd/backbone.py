@@ -124,15 +124,18 @@ class ViTS14(torch.nn.Module):
         m = int(math.isqrt(pe.shape[1] - 1))
         if m == n_side:
             return pe
-        key = (n_side, pe._version, pe.data_ptr(), str(pe.device), pe.dtype)
-        hit = self.__dict__.get("_pos_cache")
-        if hit is not None and hit[0] == key and not (torch.is_grad_enabled() and pe.requires_grad):
+        # one entry per grid size (a dict): a captured hipGraph has the address of the tensor it was captured with baked in, so an
+        # entry must stay alive while any other grid size is in use; an entry is replaced only when the parameter itself changed
+        ver = (pe._version, pe.data_ptr(), str(pe.device), pe.dtype)
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        hit = cache.get(n_side)
+        if hit is not None and hit[0] == ver and not (torch.is_grad_enabled() and pe.requires_grad):
             return hit[1]
         patch = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
         patch = F.interpolate(patch, size=(n_side, n_side), mode="bicubic", align_corners=False)
         out = torch.cat([pe[:, :1], patch.permute(0, 2, 3, 1).reshape(1, n_side * n_side, -1)], dim=1)
         if not (torch.is_grad_enabled() and pe.requires_grad):
-            self.__dict__["_pos_cache"] = (key, out.detach())
+            cache[n_side] = (ver, out.detach())
         return out
 
     def forward_features(self, x):

@@ -27,29 +27,57 @@ import torch.distributed as dist
 _SCENE_FIELDS = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
 
 
+_single_rank_group = False     # a process group of ONE rank is in use (SIXDGS_DIST_SINGLE=1): every collective still runs through the backend
+_long_group = None             # the group with the long timeout (stages one rank may spend hours in: training), created on first use
+_long_group_timeout_s = None
+
+
 def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from RANK / WORLD_SIZE / LOCAL_RANK; initialises the process group when
-    WORLD_SIZE > 1 (rendezvous through MASTER_ADDR / MASTER_PORT, 127.0.0.1 on one node)."""
+    WORLD_SIZE > 1 (rendezvous through MASTER_ADDR / MASTER_PORT, 127.0.0.1 on one node).
+
+    SIXDGS_DIST_SINGLE=1: initialise the group at WORLD_SIZE = 1 as well, so that every collective of this module
+    (broadcast_scene, broadcast_module, gather_poses, gather_results, merge_row_stats, merge_topk, kth_largest_of_union, agree, ...)
+    runs through the backend -- RCCL on device tensors with `nccl` -- on the one GPU of a test box (round 4: the only way to
+    execute the RCCL path without a multi-GPU node; tests/test_gpu_rccl_single.py)."""
+    global _single_rank_group
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    single = world == 1 and os.environ.get("SIXDGS_DIST_SINGLE") == "1"
+    if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = os.environ.get("SIXDGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
-        # The default watchdog timeout (10 min with nccl = RCCL) is shorter than what a rank may legitimately wait for in a
-        # collective: the evaluation sweep trains a missing id_module.th on rank 0 (1500 x 32 steps) while the others wait in
-        # agree().  SIXDGS_DIST_TIMEOUT_S overrides (seconds).
-        timeout = datetime.timedelta(seconds=int(os.environ.get("SIXDGS_DIST_TIMEOUT_S", str(12 * 3600))))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        # The backend's default timeout (10 min with nccl = RCCL, 30 min with gloo) stays on the default group: a rank that dies between
+        # two stages takes its peers down within minutes, not hours.  Only the stage one rank may legitimately spend hours in -- the
+        # evaluation sweep trains a missing id_module.th on rank 0 (1500 x 32 steps) while the others wait -- gets a long timeout, on
+        # its own group (agree(..., long_wait=True)).  SIXDGS_DIST_TIMEOUT_S overrides the default group's timeout (seconds).
+        kw = {}
+        if os.environ.get("SIXDGS_DIST_TIMEOUT_S"):
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ["SIXDGS_DIST_TIMEOUT_S"]))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    if single and dist.is_initialized():
+        _single_rank_group = True
     return rank, world, local
 
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_group)
+
+
+def long_wait_group():
+    """The process group for collectives a rank may wait hours in (SIXDGS_DIST_LONG_TIMEOUT_S, default 12 h).  Created collectively on
+    first use -- every rank reaches its first long-wait stage at the same point of the sweep."""
+    global _long_group, _long_group_timeout_s
+    t = int(os.environ.get("SIXDGS_DIST_LONG_TIMEOUT_S", str(12 * 3600)))
+    if _long_group is None or _long_group_timeout_s != t:
+        _long_group = dist.new_group(timeout=datetime.timedelta(seconds=t))
+        _long_group_timeout_s = t
+    return _long_group
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -167,21 +195,24 @@ def barrier():
         dist.barrier()
 
 
-def agree(fn: Callable, what: str = "", device=None):
+def agree(fn: Callable, what: str = "", device=None, long_wait: bool = False):
     """Runs the rank-local stage `fn()` (NO collectives inside) and then lets the ranks agree on whether it worked: an all-reduce
-    (MAX) of a failure flag.  A RuntimeError -- the one exception the reference's sweep survives per scene
-    (pretrain_eval_attention.py:243-244): out of memory, an unreadable scene, a missing backbone -- on ANY rank is raised on
-    EVERY rank (the failing rank re-raises its own, the others a RuntimeError naming the stage), so that all ranks leave the
-    scene together and the next scene's collectives pair up again.  Without a process group: plain fn()."""
+    (MAX) of a failure flag.  ANY exception on ANY rank reaches the all-reduce (a FileNotFoundError or KeyError out of a
+    loader used to skip it and leave the peers waiting in it): the failing rank re-raises its own exception afterwards, the others
+    raise a RuntimeError naming the stage, so that all ranks leave the stage together and the next collectives pair up again.  What
+    a sweep SURVIVES stays the caller's decision -- the reference's per-scene `except RuntimeError`
+    (pretrain_eval_attention.py:243-244) catches the peers' RuntimeError and the failing rank's own only if it is one.
+    long_wait: the stage may take hours on one rank (training on rank 0): its all-reduce runs on the group with the long timeout,
+    everything else keeps the backend's default.  Without a process group: plain fn()."""
     err, out = None, None
     try:
         out = fn()
-    except RuntimeError as e:
+    except Exception as e:              # noqa: BLE001 -- re-raised below, after the ranks have met
         err = e
     if is_dist():
         dev = "cpu" if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=long_wait_group() if long_wait else None)
         if int(flag.item()) and err is None:
             raise RuntimeError(f"6dgs_amd: another rank failed during '{what}'; rank {dist.get_rank()} leaves the scene with it")
     if err is not None:

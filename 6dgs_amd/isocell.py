@@ -35,36 +35,41 @@ def isocell_distribution(ray_target, dtype=torch.float32, device="cuda", N0: int
         if dtype != torch.float32:
             raise RuntimeError("6dgs_amd: the iso-cell directions are computed in fp32 (the reference's dtype on this path)")
         return ops.isocell_distribution(int(ray_target), int(N0), device=device)
-    if isrand not in (1, 2, 3, 4):
-        raise ValueError(f"isrand must be -1 or 1..4, got {isrand}")
+    # Every other value of isrand takes the reference's random start angle; 1..4 add their per-cell jitter, anything else centres the cells in
+    # radius and angle (isocell.py:61-63, the reference's else-branch -- ADVICE r3: this used to raise ValueError here).  All draws come from
+    # the generator of `device`, in the reference's order (isocell.py:24,47-60 pass device=device): a CPU seed reproduces the reference bit for
+    # bit (golden g13), a CUDA seed reproduces torch's device generator as the reference would use it.
     n = _rings(ray_target, N0)
-    u0 = torch.rand(1, dtype=dtype)                       # (the reference draws th0 before it looks at isrand)
+    u0 = torch.rand(1, dtype=dtype, device=device)        # (the reference draws th0 before it looks at isrand)
     if n != 1:
         raise RuntimeError(f"The size of tensor a ({n}) must match the size of tensor b ({N0 * n * n}) at non-singleton dimension 0 "
                            "(isocell.py:44 adds a per-ring offset to a per-cell vector: the random modes exist for one ring only)")
     cells = N0                                            # one ring of N0 cells, radius step dR = 1
-    dth = 2 * math.pi / torch.tensor([float(cells)], dtype=dtype)   # (a tensor, so that the fp32 rounding is the reference's)
-    start = u0 * dth + torch.arange(cells, dtype=dtype) * dth           # [cells]
-    radius = torch.ones(cells, dtype=dtype)
+    dth = 2 * math.pi / torch.tensor([float(cells)], dtype=dtype, device=device)   # (a tensor, so that the fp32 rounding is the reference's)
+    start = u0 * dth + torch.arange(cells, dtype=dtype, device=device) * dth           # [cells]
+    radius = torch.ones(cells, dtype=dtype, device=device)
 
     def half_gauss():
-        return (1 + torch.randn(1, cells, dtype=dtype) / 6.5) / 2
+        return (1 + torch.randn(1, cells, dtype=dtype, device=device) / 6.5) / 2
 
     if isrand == 1:
-        radius = radius - torch.rand(1, cells, dtype=dtype) * 1.0
-        theta = start + torch.rand(1, cells, dtype=dtype) * dth
+        radius = radius - torch.rand(1, cells, dtype=dtype, device=device) * 1.0
+        theta = start + torch.rand(1, cells, dtype=dtype, device=device) * dth
     elif isrand == 2:
-        radius = radius - torch.rand(1, cells, dtype=dtype) * 1.0
+        radius = radius - torch.rand(1, cells, dtype=dtype, device=device) * 1.0
         theta = start + dth / 2
     elif isrand == 3:
         radius = radius - half_gauss() * 1.0
         theta = start + half_gauss() * dth / 2
-    else:
+    elif isrand == 4:
         radius = radius - half_gauss() * 1.0
+        theta = start + dth / 2
+    else:
+        radius = radius - 1.0 / 2                         # (1-D here: the reference's result is [cells, 3] in this branch, [1, 3 cells] in modes 1-4)
         theta = start + dth / 2
     x, y = radius * torch.cos(theta), radius * torch.sin(theta)
     z = torch.real(torch.sqrt(1 - torch.square(x.to(torch.complex64)) - torch.square(y.to(torch.complex64))))
-    return torch.column_stack([x, y, z]).to(device)
+    return torch.column_stack([x, y, z])
 
 
 def rotate_isocell(isocell_directions: torch.Tensor, normal: torch.Tensor) -> torch.Tensor:

@@ -78,7 +78,7 @@ def pretrain_single_object(checkpoint_filepath: str, checkpoint_args: "dotdict[s
     Multi-rank: the scene is walked in STAGES.  A stage is rank-local work that may fail (`dd.agree`: the ranks all-reduce a
     failure flag behind it and leave the scene TOGETHER on a RuntimeError of any of them); the collectives (scene / weight
     broadcast, seed, result gather) sit between the stages, where every rank is known to arrive.  Rank 0 trains a missing
-    checkpoint inside a stage while the others wait in that stage's all-reduce (the process group's timeout is set for it,
+    checkpoint inside a stage while the others wait in that stage's all-reduce (on the group with the long timeout: agree(long_wait=True),
     distributed.init_from_env)."""
     torch.manual_seed(starting_seed)
     print("data_path: ", checkpoint_args.source_path)
@@ -108,7 +108,7 @@ def pretrain_single_object(checkpoint_filepath: str, checkpoint_args: "dotdict[s
             train_id_module(ckpt_path, device, id_module, partial(explore_model, gs_model, **emission), scene_info, object_id, category_name,
                             start_iterations=start_iterations, lock_backbone=lock_backbone, n_iterations=n_iterations)
 
-    dd.agree(stage_train, "train the scorer (rank 0)", device)
+    dd.agree(stage_train, "train the scorer (rank 0)", device, long_wait=True)
     dd.broadcast_module(id_module, 0)
     id_module.eval()
     id_module.invalidate_caches()

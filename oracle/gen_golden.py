@@ -681,7 +681,7 @@ def g12(m):
 def g13(m):
     iso = m["isocell"]
     out, raises = {}, []
-    for mode in (1, 2, 3, 4):
+    for mode in (1, 2, 3, 4, 0, 7):          # 0, 7: any other value of isrand takes the else-branch (:61-63): random start angle, centred cells
         for tgt, n0 in ((1, 1), (3, 3), (4, 1), (64, 1), (35, 3)):
             torch.manual_seed(1300 + 10 * mode + n0)
             try:

@@ -77,6 +77,23 @@ def _worker(rank, world, port, q):
         t = torch.tensor([float(rank + 1)])
         torch.distributed.broadcast(t, 0)                 # the next scene's first collective pairs up again
         assert float(t) == 1.0
+        # 6. an exception that is NOT a RuntimeError -- a loader's FileNotFoundError, a checkpoint's KeyError -- reaches the
+        #    all-reduce as well: the failing rank re-raises its own, the peer gets the RuntimeError; and a long-wait stage (rank 0 trains)
+        #    runs its all-reduce on the group with the long timeout while the default group keeps the backend's default
+        def stage_io():
+            if rank == 1:
+                raise FileNotFoundError("cameras.json")
+            return "loaded"
+
+        try:
+            dd.agree(stage_io, "load")
+            raised = None
+        except (RuntimeError, FileNotFoundError) as e:
+            raised = e
+        assert isinstance(raised, FileNotFoundError if rank == 1 else RuntimeError), raised
+        assert dd.agree(lambda: "trained", "train", long_wait=True) == "trained"
+        assert dd.long_wait_group() is dd.long_wait_group()
+        torch.distributed.broadcast(t, 0)
         dd.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover

@@ -24,10 +24,9 @@ def test_random_modes_raise_where_the_reference_raises_and_match_it_for_one_ring
         else:
             d = iso.isocell_distribution(tgt, torch.float32, "cpu", N0=n0, isrand=mode)
             want = g13[f"rand_m{mode}_t{tgt}_n{n0}"]
-            assert tuple(d.shape) == want.shape                       # [1, 3 N0]: x.., y.., z.. (the reference's column_stack of [1,N0] rows)
-            assert np.array_equal(d.numpy(), want), (mode, tgt, n0)   # same generator, same draw order: bit-exact on CPU
-    with pytest.raises(ValueError):
-        iso.isocell_distribution(4, torch.float32, "cpu", isrand=7)
+            assert tuple(d.shape) == want.shape                       # modes 1-4: [1, 3 N0]: x.., y.., z.. (the reference's column_stack of [1,N0] rows);
+            assert np.array_equal(d.numpy(), want), (mode, tgt, n0)   # any other mode (0, 7: the else-branch): [N0, 3].  Same generator, same draw order: bit-exact on CPU
+    assert {int(m) for m in g13["raises"][:, 0]} == {0, 1, 2, 3, 4, 7}
 
 
 def test_random_mode_consumes_the_generator_like_the_reference_before_raising():
@@ -71,11 +70,18 @@ def test_module_surface_on_the_gpu_is_the_hip_path():
     assert torch.equal(iso.rotate_isocell(d, n), ops.rotate_isocell(d, n))
     with pytest.raises(RuntimeError):
         iso.isocell_distribution(64, torch.float64, "cuda")
-    torch.manual_seed(1311)
-    r = iso.isocell_distribution(1, torch.float32, "cuda", N0=1, isrand=1)
-    assert r.is_cuda and tuple(r.shape) == (1, 3)
+    # random modes on the GPU draw from the DEVICE generator, as the reference does (isocell.py:24,47-60 pass device=device): reproducible
+    # under a CUDA seed, on the unit hemisphere, and not the CPU stream's numbers (the golden pins the CPU generator only)
     g = np.load(G)
-    assert np.array_equal(r.cpu().numpy(), g["rand_m1_t1_n1"])       # drawn from the CPU generator: the reference's CPU result
+    torch.manual_seed(1311)
+    r = iso.isocell_distribution(3, torch.float32, "cuda", N0=3, isrand=1)
+    torch.manual_seed(1311)
+    r2 = iso.isocell_distribution(3, torch.float32, "cuda", N0=3, isrand=1)
+    assert r.is_cuda and tuple(r.shape) == (1, 9) and torch.equal(r, r2)
+    xyz = r.reshape(3, 3)
+    assert torch.allclose((xyz * xyz).sum(0), torch.ones(3, device="cuda"), atol=1e-6) and bool((xyz[2] >= 0).all())
+    c = iso.isocell_distribution(3, torch.float32, "cuda", N0=3, isrand=7)          # the else-branch: centred cells, [N0, 3]
+    assert tuple(c.shape) == (3, 3) and torch.allclose(c[:, :2].norm(dim=1), torch.full((3,), 0.5, device="cuda"), atol=1e-6)
     dirs = torch.from_numpy(g["grp_27_3_dirs"]).cuda()
     grp, ring, cell = iso.group_by_360_isocell(dirs, 27, N0=3)
     assert grp.is_cuda and np.array_equal(grp.cpu().numpy(), g["grp_27_3_group"])
