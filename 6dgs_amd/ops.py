@@ -388,6 +388,18 @@ def split_planes_f16(x: torch.Tensor):
 # rays per launch of the ray-MLP chain: 2^20 (6.9 GB of workspace).  A persistent workgroup then walks ~32 tile passes per launch instead of 8, and
 # the chain runs 3-4 % faster than with 2^18 (fewer launch tails); any chunking gives the same keys bit for bit.
 RAY_KEYS_CHUNK = 1 << 20
+RAY_KEYS_CHUNK_MIN = 1 << 16
+
+
+def _free_bytes(dev) -> int:
+    """Device memory a new tensor can still get: what the driver reports free + what PyTorch's caching allocator holds unused."""
+    free = torch.cuda.mem_get_info(dev)[0]
+    return int(free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+
+
+def ray_keys_workspace_bytes(r: int, max_chunk: int = RAY_KEYS_CHUNK) -> int:
+    """Transient workspace of one ray_keys call over r rays (callers that budget HBM: bench.py's residency guard, the streamed scorer)."""
+    return int(_lib.load().sixdgs_ray_keys_workspace_bytes(int(r), int(max_chunk)))
 
 
 @_on_device
@@ -409,6 +421,13 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     planes = torch.empty(r, 1536 if f16 else 2304, dtype=torch.uint8, device=dev) if want_planes else None
     inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
+    if workspace is None or workspace.numel() < nbytes:
+        # 6560 B of transient workspace per ray of a chunk (6.9 GB at the default 2^20 rays): next to a scene that nearly fills the HBM the
+        # chunk shrinks instead of the allocation failing -- any chunking gives the same keys bit for bit, smaller chunks are 3 % slower
+        chunk = int(max_chunk)
+        while chunk > RAY_KEYS_CHUNK_MIN and nbytes > 0.5 * _free_bytes(dev):
+            chunk //= 2
+            nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, chunk)
     ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if norm_out is not None and not f16:
         raise RuntimeError("6dgs_amd: norm_out needs scaled fp16 key planes (want_planes in MMA_F16X3 mode)")

@@ -113,7 +113,7 @@ def pretrain_single_object(checkpoint_filepath: str, checkpoint_args: "dotdict[s
     id_module.eval()
     id_module.invalidate_caches()
     print("Training complete starting testing phase...")
-    if dd.world() > 1:       # every rank must emit the SAME rays (the subsample is a torch.randperm): one seed from rank 0's generator
+    if dd.is_dist():         # every rank must emit the SAME rays (the subsample is a torch.randperm): one seed from rank 0's generator
         torch.manual_seed(dd.broadcast_int(int(torch.randint(0, 2**31 - 1, (1,)).item()), 0, device))
     lo, hi = dd.shard_range(len(scene_info.test_cameras), dd.rank(), dd.world())
 
@@ -166,6 +166,8 @@ def main(argv=None, backbone: Optional[torch.nn.Module] = None) -> List[dict]:
         raise RuntimeError("6dgs_amd: the evaluation sweep needs an MI355X (no CPU fallback on the product path)")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
+    if dd.is_dist() and rank == 0:
+        print(f"[6dgs_amd] evaluation sweep over {dd.ranks_seen(torch.device(device))} rank(s), backend {dd.backend_name()}")
     results: List[dict] = []
     for exp in parse_exp_dir(args.exp_path, PREFIXES.get(args.data_type, "")).values():
         ckpt_args = get_checkpoint_arguments(exp["exp_dir_filepath"])

@@ -189,11 +189,12 @@ def main():
     t_emit = time.time() - t0
     R = int(ori.shape[0])
     ray_offset, R_total = 0, R
-    if ray_sharded and world > 1:               # this rank's rays are [ray_offset, ray_offset + R) of R_total
+    if ray_sharded and dd.is_dist():            # this rank's rays are [ray_offset, ray_offset + R) of R_total
         counts = dd.all_counts(R, dev)
         ray_offset, R_total = sum(counts[:rank]), sum(counts)
     streamed = args.scoring == "streamed"
-    if not streamed and R * 1536 > 0.9 * torch.cuda.mem_get_info(dev)[0]:
+    # resident key planes (1536 B per ray) + the ray-MLP chain's transient workspace at its smallest chunk (it shrinks its chunk when memory is tight)
+    if not streamed and R * 1536 + ops.ray_keys_workspace_bytes(R, ops.RAY_KEYS_CHUNK_MIN) > 0.9 * torch.cuda.mem_get_info(dev)[0]:
         raise SystemExit(f"rank {rank}: the key planes of {R} rays ({R * 1536 / 2**30:.0f} GiB) do not fit this GPU: use --scoring streamed, or --parallelism ray on more GPUs")
     kprof = ops.KernelProfile()
     t0 = time.time()
@@ -269,7 +270,7 @@ def main():
             return sol["c2w"].cpu(), sol
         if "packed" in sol:                                      # graph / deferred status: poses + select statuses in ONE D2H
             c2w_local = tp.resolve_poses(idm, sol, sol["packed"].cpu())
-            if world == 1:
+            if not dd.is_dist():
                 return c2w_local, sol
             c2w, st = dd.gather_poses(c2w_local.to(dev), sol["status"], 0)
             return (c2w if c2w is not None else c2w_local).cpu(), sol

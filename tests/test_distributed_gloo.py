@@ -200,3 +200,36 @@ def test_two_rank_gloo_ray_sharded_merges():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _single_worker(port, q):
+    try:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIXDGS_DIST_SINGLE="1")
+        import importlib
+        import torch
+        dd = importlib.import_module("6dgs_amd.distributed")
+        assert not dd.is_dist()
+        assert dd.init_from_env("gloo") == (0, 1, 0)
+        assert dd.is_dist() and dd.backend_name() == "gloo" and dd.world() == 1 and dd.ranks_seen("cpu") == 1
+        assert dd.all_counts(7, "cpu") == [7] and dd.max_over_ranks(2.5, "cpu") == 2.5
+        c2w, st = dd.gather_poses(torch.eye(4)[None], torch.tensor([3], dtype=torch.int32), 0)
+        assert c2w.shape == (1, 4, 4) and st.tolist() == [3]
+        assert dd.gather_results([{"a": 1}]) == [{"a": 1}] and dd.agree(lambda: 5, "x") == 5 and dd.agree(lambda: 6, "y", long_wait=True) == 6
+        dd.barrier()
+        q.put("ok")
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put("FAIL: " + traceback.format_exc())
+
+
+@pytest.mark.timeout(120)
+def test_single_rank_group_runs_every_collective_through_the_backend():
+    """SIXDGS_DIST_SINGLE=1: a process group of ONE rank (round 4: how the RCCL path runs on the one-GPU box, tests/test_gpu_rccl_single.py);
+    here over gloo: is_dist() turns true and the helpers take their collective branches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=100)
+    p.join(30)
+    assert res == "ok", res

@@ -65,9 +65,9 @@ def main():
     val_rel = float(((gval - val0).abs().max() / val0.abs().max()).item())
     out = {"rank": rank, "world": world, "rays": [lo, hi], "scores_rel_err": rel, "topk_idx_equal": same_idx, "topk_val_rel_err": val_rel}
     gathered = [None] * world
-    torch.distributed.all_gather_object(gathered, out) if world > 1 else gathered.__setitem__(0, out)
+    torch.distributed.all_gather_object(gathered, out) if dd.is_dist() else gathered.__setitem__(0, out)
     if rank == 0:
-        print(json.dumps({"ranks": gathered, "ok": all(g["topk_idx_equal"] and g["scores_rel_err"] < 2e-6 and g["topk_val_rel_err"] < 2e-6
+        print(json.dumps({"ranks": gathered, "backend": dd.backend_name(), "ok": all(g["topk_idx_equal"] and g["scores_rel_err"] < 2e-6 and g["topk_val_rel_err"] < 2e-6
                                                           for g in gathered)}), flush=True)
     dd.barrier()
 
@@ -108,14 +108,14 @@ def check_select(a, dd, ops, rank, world, dev, key, q, n, n_tok):
     out = {"rank": rank, "world": world, "rays": [lo, hi], "single_gpu_status": st0.tolist(), "single_gpu_select_equals_two_pass_set":
            [bool(set(idx0[b].tolist()) == set(i2[b].tolist())) for b in range(q.shape[0])], **res}
     gathered = [None] * world
-    torch.distributed.all_gather_object(gathered, out) if world > 1 else gathered.__setitem__(0, out)
+    torch.distributed.all_gather_object(gathered, out) if dd.is_dist() else gathered.__setitem__(0, out)
     if rank == 0:
         # "select": the same 100 rays; "forced_fallback": the softmax is flat to ~1e-4, the 100th and 101st scores tie within fp32 rounding,
         # so the SETS may differ between two correct evaluations -- the sorted value lists must not
         ok = all(all(g["select"]["same_set"]) and g[m]["val_rel_err"] < 2e-6 for g in gathered for m in ("select", "forced_fallback"))
         ok = ok and all(min(g["select"]["status"]) >= 100 and g["select"]["redo"] == [] for g in gathered)
         ok = ok and all(len(g["forced_fallback"]["redo"]) >= 2 for g in gathered)      # (the one-token image may still be decidable)
-        print(json.dumps({"ranks": gathered, "ok": bool(ok)}), flush=True)
+        print(json.dumps({"ranks": gathered, "backend": dd.backend_name(), "ok": bool(ok)}), flush=True)
     dd.barrier()
 
 
