@@ -692,6 +692,32 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       const int lim_next = has_next ? tile_lim(tile + 1) : lim_cur;
       // the 12 slabs are fully unrolled; keep the per-slab source addresses from being hoisted out of the tile loop
       asm volatile("" : "+v"(offQ[0]), "+v"(offQ[1]), "+v"(offQ[2]), "+v"(offQ[3]), "+v"(offK[0]), "+v"(offK[1]), "+v"(offK[2]), "+v"(offK[3]));
+      // ---- token-aware (round 4): a wave whose 64-token row block lies at or beyond the image's token count (masked Tanks&Temples / Blender views
+      // keep 56-140 of 256 tokens, backbone.py:86-114) has nothing to compute: it skips the tile's 576 MFMAs, fragment reads and accumulators and only
+      // does its share of the workgroup's data movement -- per slab the same counted wait, the same barrier and the same 8 DMA pieces in the same
+      // order as the waves that compute (vmcnt bookkeeping unchanged), issued right behind the barrier.  Wave-uniform branch; waves 0-3 (token rows
+      // 0-127) sit on the four SIMDs, so an image of <= 128 tokens leaves every SIMD with ONE computing wave and half the matrix work.
+      if (!active && !(ABL & 4096)) {
+        int ks3 = 0;                                 // sl % 3 (a ROLLED loop with run-time stages: unrolled, its 96 piece addresses cost the computing
+#pragma unroll 1                                     // waves registers -- 41 spilled VGPRs in the first build)
+        for (int sl = 0; sl < 12; ++sl) {
+          const int qs = sl & 1;
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          const int sq = sl + 2 < 12 ? sl + 2 : sl + 2 - 12;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issue_q(sq, qs, i);
+          const bool nxt = sl + 3 >= 12;
+          const char* kb = nxt ? knext : kcur;
+          const int kl = nxt ? lim_next : lim_cur, sk = nxt ? sl + 3 - 12 : sl + 3;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issue_k(kb, kl, sk, ks3, i);
+          ks3 = ks3 == 2 ? 0 : ks3 + 1;
+        }
+        kcur = knext;
+        lim_cur = lim_next;
+        continue;
+      }
       f32x16 acc[2][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -2255,8 +2281,18 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
       grid = (unsigned)(V.n_sets * batch);
     }
     SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + batch * 16.0));
-    if (V.n_sets > 0) hipLaunchKernelGGL((k_logits_f16x<0, kOutUB, true>), dim3(grid), dim3(512), 0, s, V);
-    else hipLaunchKernelGGL((k_logits_f16x<0, kOutUB, false>), dim3(grid), dim3(512), 0, s, V);
+    auto kern = V.n_sets > 0 ? k_logits_f16x<0, kOutUB, true> : k_logits_f16x<0, kOutUB, false>;
+#ifdef SIXDGS_ABLATION   // timing / power experiments only (tools/power_trace.py abl<N> on a private -DSIXDGS_ABLATION build): the sweep with parts compiled out
+    if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
+#define SDG_ABL_CASE(n) case n: kern = V.n_sets > 0 ? k_logits_f16x<n, kOutUB, true> : k_logits_f16x<n, kOutUB, false>; break;
+      switch (atoi(ab)) {
+        SDG_ABL_CASE(2) SDG_ABL_CASE(18) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59) SDG_ABL_CASE(4096)
+        default: break;
+      }
+#undef SDG_ABL_CASE
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, V);
   }
   hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch, 4), dim3(1024), 0, s, w.partial, V.n_groups, w.stats);
   hipLaunchKernelGGL(k_sel_accumulate, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, gsum);

@@ -15,6 +15,8 @@ The other presets are BASELINE.json's `configs` entries (sizes per SURVEY.md §8
   cfg2  300 k Gaussians read back from a 3DGS PLY, x 64 rays, one query  (configs[1])
   cfg3  1 M Gaussians x 64 = 64 M rays, 8 images per GPU                  (configs[2]: 64 views over 8 GPUs)
   cfg4  2 M Gaussians x 256 = 512 M rays, 16 images per GPU, key cache does not fit: streamed scorer   (configs[3])
+  cfg5-standin  the reference's 12-scene evaluation sweep at ITS scale with synthetic stand-ins (configs[4]: 0.3-6.1 M Gaussians per scene, 16-48
+        test views each, masked RGBA views for the Tanks&Temples scenes; per-scene poses/s, one view per scene oracle-checked): tools/cfg5_standin.py
 One step = one pass of the hot path over one batch: image prep -> ViT-S/14 tokens + camera-up CNN (PyTorch-ROCm,
 random init: DINOv2 weights are not downloadable) -> q_proj -> ray<->token scorer over the cached key planes -> top-100
 -> pose solve -> c2w on the host.  Scene set-up (normals, emission, ray MLP + k_proj key cache) happens once per
@@ -55,6 +57,8 @@ PRESETS = {
     "cfg2": dict(gaussians=300_000, rays_per_ellipsoid=64, batch=1, image_size=800, scene="ply", scoring="resident"),
     "cfg3": dict(gaussians=1_000_000, rays_per_ellipsoid=64, batch=8, image_size=800, scene="synthetic", scoring="resident"),
     "cfg4": dict(gaussians=2_000_000, rays_per_ellipsoid=256, batch=16, image_size=800, scene="synthetic", scoring="streamed"),
+    # configs[4] at its scale with synthetic stand-ins: 12 scenes at the Mip-NeRF360 / Tanks&Temples sizes, all test views (tools/cfg5_standin.py)
+    "cfg5-standin": dict(gaussians=0, rays_per_ellipsoid=64, batch=16, image_size=800, scene="synthetic", scoring="resident"),
 }
 
 
@@ -97,6 +101,11 @@ def parse():
     ap.add_argument("--skip-reference-mode", action="store_true", help="skip the secondary reference-mode figure (1000-ellipsoid quadricell emission)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    ap.add_argument("--scenes", default="", help="cfg5-standin: comma-separated substrings of the scene names to run (default: all twelve)")
+    ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
+    ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
+    ap.add_argument("--streamed-batch", type=int, default=32, help="cfg5-standin: images per step of a streamed scene (one pass of the ray MLP serves them all)")
+    ap.add_argument("--oracle-rays", type=int, default=1 << 20, help="cfg5-standin: rays of the per-scene oracle check (a prefix of the scene)")
     args = ap.parse_args()
     for k, v in PRESETS[args.config].items():
         if getattr(args, k) is None:
@@ -145,6 +154,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
+    if args.config == "cfg5-standin":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cfg5_standin
+        idm = pkg.IdentificationModule("dino")
+        idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
+        idm = idm.to(dev).eval()
+        dd.broadcast_module(idm, 0)
+        out = cfg5_standin.run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, PEAK_16BIT_MFMA_TFLOPS)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dd.barrier()
+        return
     ranks_seen = dd.ranks_seen(dev)          # an all-reduce of ones over the process group (RCCL when world > 1)
 
     # ---- scene: rank 0 owns it, RCCL broadcast of the Gaussian arrays, local re-emission ------------------

@@ -101,3 +101,24 @@ def test_bench_presets_cfg1_cfg2_and_streamed_scorer():
     d = _run([sys.executable, "-W", "ignore", "bench.py", "--config", "cfg4", "--gaussians", "4000", "--batch", "3", "--chunk-rays", "300000",
               "--steps", "1", "--skip-cpu-baseline"])
     assert d["config"]["scoring"] == "streamed" and d["config"]["rays"] == 4000 * 256 and d["roofline"]["launches"] >= 8
+
+
+@pytest.mark.timeout(900)
+def test_bench_cfg5_standin_sweep_at_reduced_scale():
+    """BASELINE.json configs[4] as a bench preset (tools/cfg5_standin.py): the twelve scenes of the reference's sweep, here at 1/50 of their
+    Gaussian counts and 3 views each -- per-scene rows, masked T&T views keep a subset of the tokens, one view per scene agrees with the
+    oracle (top-100 identical through both scorers, pose within north_star's 1e-4).  The full-size run is a bench command, not a test."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run([sys.executable, "-W", "ignore", "bench.py", "--config", "cfg5-standin", "--scale", "0.02", "--views-cap", "3", "--oracle-rays", "131072"], timeout=800)
+    assert d["config"]["preset"] == "cfg5-standin" and len(d["scenes"]) == 12 and d["config"]["test_views"] == 36 and d["value"] > 0
+    names = [r["scene"] for r in d["scenes"]]
+    assert names[0] == "mip_360_bicycle" and names[-1] == "tt_Truck"
+    for r in d["scenes"]:
+        assert 0.8 * 64 * r["gaussians"] < r["rays"] <= 64 * r["gaussians"] and r["poses_per_s"] > 0
+        lo, hi = r["tokens_per_image_min_max"]
+        assert (hi < 256 and lo >= 1) if r["masked"] else (lo == hi == 256)
+        p = r["parity_vs_oracle"]
+        assert p["top100_identical_two_pass"] and p["top100_identical_select"] and p["score_rel_err"] < 1e-5 and p["pose_rel_err"] < 1e-4, (r["scene"], p)
+    assert d["parity_summary"]["scenes_checked"] == 12 and d["parity_summary"]["all_top100_identical"]
+    assert d["roofline"]["frac"] is not None and d["cpu_baseline"]["kind"] == "port"

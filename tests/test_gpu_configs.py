@@ -82,6 +82,48 @@ def host_keys(env, ori, dr, rgb, chunk=4_000_000):
     return out
 
 
+def sampled_key_parity(oracle, env, ori, dr, rgb, planes, inv, what, launch_rays=None, sample=None, n_stride=32768):
+    """The ORACLE's ray MLP + k_proj (ray_preprocessor.py:11-46, our_multihead_attention.py:74 restated in C) on >= 32 k rays spread over the
+    WHOLE scene against the HIP key planes the scorer actually streams (reconstructed (h + l) x the 128-ray tile's scale) -- VERDICT r3 #2:
+    until round 4 the full-size configs fed the oracle GPU-produced keys, and the chain itself met the oracle at R <= 300 037 only.
+    The sample: a uniform stride over all rays; the first / second / 128th / 129th and the last two rays of EVERY launch of the chain
+    (`launch_rays` rays each: 125-2000 launches at these sizes); every ray of the ragged last tiles; and (sample=(indices, planes, inv)) a
+    stride of the select path's ray sample, checked against ITS planes (a second pass of the chain over gathered rays)."""
+    ops = env["ops"]
+    R = int(ori.shape[0])
+    L = int(launch_rays or ops.RAY_KEYS_CHUNK)
+    picks = [np.linspace(0, R - 1, n_stride).astype(np.int64), np.arange(max(0, R - 300), R, dtype=np.int64)]
+    starts = np.arange(0, R, L, dtype=np.int64)
+    ends = np.minimum(starts + L, R)
+    picks += [starts, np.minimum(starts + 1, R - 1), np.minimum(starts + 127, R - 1), np.minimum(starts + 128, R - 1), ends - 1, np.maximum(ends - 2, 0)]
+    idx_np = np.unique(np.concatenate(picks))
+    idx = torch.from_numpy(idx_np).cuda()
+
+    def hip_rows(pl, iv, rows):
+        p = pl[rows].contiguous().view(torch.float16).view(-1, 12, 2, 32).float()
+        return ((p[:, :, 0] + p[:, :, 1]).reshape(-1, 384) * iv[rows // 128][:, None]).cpu().numpy()
+
+    t0 = time.time()
+    _, okey = oracle.ray_features(ori[idx].cpu().numpy(), dr[idx].cpu().numpy(), rgb[idx].cpu().numpy(), env["sd"], want_feat=False)
+    dt = time.time() - t0
+    hkey = hip_rows(planes, inv, idx)
+    tile_max = np.abs(hkey).max()                                  # (the sampled rows' largest element: rows far below their tile's scale are held to it / 64)
+    den = np.maximum(np.abs(okey).max(axis=1), tile_max / 64)
+    err = np.abs(hkey - okey).max(axis=1) / den
+    assert np.isfinite(hkey).all() and err.max() < 5e-6, f"{what}: key planes differ from the oracle's ray MLP + k_proj by {err.max():.2e} (row {idx_np[err.argmax()]})"
+    msg = f"[{what}] key parity: {idx_np.shape[0]} rays of {R} ({starts.shape[0]} chain launches of {L}), oracle {dt:.1f} s, max row error {err.max():.2e}"
+    if sample is not None:
+        s_idx, s_pl, s_inv = sample
+        sel = torch.arange(0, s_idx.shape[0], max(1, s_idx.shape[0] // 4096), device="cuda")
+        rows = s_idx[sel]
+        _, okey_s = oracle.ray_features(ori[rows].cpu().numpy(), dr[rows].cpu().numpy(), rgb[rows].cpu().numpy(), env["sd"], want_feat=False)
+        hs = hip_rows(s_pl, s_inv, sel)
+        es = np.abs(hs - okey_s).max(axis=1) / np.maximum(np.abs(okey_s).max(axis=1), np.abs(hs).max() / 64)
+        assert es.max() < 5e-6, f"{what}: the select path's sample planes differ from the oracle by {es.max():.2e}"
+        msg += f"; select sample: {sel.shape[0]} of {s_idx.shape[0]} rays, {es.max():.2e}"
+    print(msg)
+
+
 def oracle_check(oracle, env, key_np, tok_np, hip_scores, hip_idx, hip_val, what):
     """scores [R] and top-100 of ONE image against the oracle on the same keys and tokens."""
     t0 = time.time()
@@ -129,6 +171,9 @@ def test_headline_500k_x64_scores_and_top100_against_the_oracle(env, oracle):
     for b in range(2):
         assert set(i_s[b].tolist()) == set(idx[b].tolist())
         assert float((v_s[b] - sc[b][i_s[b]]).abs().max() / val[b][0]) < 2e-5
+    kc = idm._key_cache
+    sampled_key_parity(oracle, env, ori, dr, rgb, kc["planes"], kc["scale"], "headline 500k x 64",
+                       sample=(ops.select_sample_indices(ori.shape[0], "cuda"), kc["sample"][0], kc["sample"][1]))
     key_np = host_keys(env, ori, dr, rgb)
     s_ref = oracle_check(oracle, env, key_np, toks[0], sc[0].cpu().numpy(), idx[0].cpu().numpy(), val[0].cpu().numpy(), "headline 500k x 64")
     # ... and the select path's answer against the same oracle scores
@@ -218,6 +263,8 @@ def test_cfg3_1m_x64_eight_images_per_rank_grouped(env, oracle):
     b = 2                   # 137 tokens: ragged token count + about half the oracle time of a full image
     s_b, i_b, v_b = sc[b].cpu().numpy(), idx[b].cpu().numpy(), val[b].cpu().numpy()
     del sc, ws
+    sampled_key_parity(oracle, env, ori, dr, rgb, kc["planes"], kc["scale"], "cfg-3 1M x 64",
+                       sample=(ops.select_sample_indices(R, "cuda"), kc["sample"][0], kc["sample"][1]))
     key_np = host_keys(env, ori, dr, rgb)
     oracle_check(oracle, env, key_np, toks[b].cpu().numpy(), s_b, i_b, v_b, "cfg-3 1M x 64, image 2 of 8")
     assert kc["planes"].shape[0] == R
@@ -249,6 +296,18 @@ def test_cfg4_2m_x256_rank_share_and_whole_scene_streamed(env, oracle):
         assert float((v_st[b] - v_rs[b]).abs().max() / v_rs[b].max()) < 2e-6                            # ... same values up to the rounding of sum-exp
     s_1, i_1, v_1 = sc[1].cpu().numpy(), i_st[1].cpu().numpy(), v_st[1].cpu().numpy()
     del sc
+    kc = idm._key_cache
+    sampled_key_parity(oracle, env, o_s, d_s, c_s, kc["planes"], kc["scale"], "cfg-4 rank share 64M rays (256 rays per ellipsoid)")
+    # ... and the chunks of the WHOLE scene's streamed sweep: the chain over three of its 64 chunks (first, one in the middle, the ragged last), each
+    # checked over its own launches (what score_tokens_streamed computes, uses and drops)
+    wts = idm.packed_weights("cuda")
+    for c0 in (0, 31 * 8_388_608, (R // 8_388_608) * 8_388_608):
+        c1 = min(c0 + 8_388_608, R)
+        if c1 <= c0:
+            continue
+        _, _, (pl_c, inv_c) = ops.ray_keys(ori[c0:c1], dr[c0:c1], rgb[c0:c1], wts, want_key=False, want_planes=True)
+        sampled_key_parity(oracle, env, ori[c0:c1], dr[c0:c1], rgb[c0:c1], pl_c, inv_c, f"cfg-4 streamed chunk at ray {c0}", n_stride=4096)
+        del pl_c, inv_c
     idm.invalidate_caches()
     key_np = host_keys(env, o_s, d_s, c_s)
     s_ref = oracle_check(oracle, env, key_np, toks[1].cpu().numpy(), s_1, i_1, v_1, "cfg-4 rank share 64M rays (streamed cut)")

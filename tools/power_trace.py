@@ -3,7 +3,9 @@
     python tools/power_trace.py <workload> [seconds]      workload = idle | sweep | chain | mfma | copy
       sweep : sixdgs_select_sweep (k_logits_f16x<kOutUB>), 4 images x 32 M rays of random key planes
       chain : sixdgs_ray_keys_ex (encode + five k_dense_planes launches per chunk), 8 M rays
-      mfma  : the two-pass logits kernel of an -DSIXDGS_ABLATION build with everything but its MFMAs compiled out
+      mfma  : the sweep of an -DSIXDGS_ABLATION build with everything but its MFMAs compiled out (= abl59)
+      abl<N>: the sweep under compile-time ablation N (0 full, 2 no epilogue, 18 no fragment reads + no epilogue, 11 no DMA + no epilogue,
+              27 MFMA + barriers, 59 MFMA only; names in tools/ablate_logits.py)
               (SIXDGS_LIB must point at build/variants/lib_abl.so: python tools/build_variant.py abl -DSIXDGS_ABLATION)
       copy  : torch copy of 8 GB (HBM only, no matrix pipe)
 
@@ -111,7 +113,8 @@ def main():
         ops = importlib.import_module("6dgs_amd.ops")
         syn = importlib.import_module("6dgs_amd.synthetic")
         torch.manual_seed(0)
-        if wl in ("sweep", "mfma"):
+        abl = 59 if wl == "mfma" else (int(wl[3:]) if wl.startswith("abl") else None)
+        if wl == "sweep" or abl is not None:
             B, R = 4, int(os.environ.get("POWER_RAYS", 32_000_000))
             planes = torch.empty(R, 1536, dtype=torch.uint8, device="cuda")
             scale = torch.empty((R + 127) // 128, device="cuda")
@@ -122,26 +125,18 @@ def main():
                 scale[r0 // 128:r0 // 128 + s.shape[0]] = s
             q = torch.randn(B, 256, 384, device="cuda")
             nt = torch.full((B,), 256, dtype=torch.int32, device="cuda")
-            if wl == "sweep":
-                si = ops.select_sample_indices(min(R, 1 << 22), "cuda")
-                sp = planes[si].contiguous()
-                _, ssc = ops.split_planes_f16(torch.randn(si.shape[0], 384, device="cuda") * 0.07)
-                ss = ops.SelectStream(q, nt, R, 100, 4096, [256] * B)
-                ss.begin(sp, ssc)
-                fl = 2.0 * 256 * 384 * R * B
+            si = ops.select_sample_indices(min(R, 1 << 22), "cuda")
+            sp = planes[si].contiguous()
+            _, ssc = ops.split_planes_f16(torch.randn(si.shape[0], 384, device="cuda") * 0.07)
+            ss = ops.SelectStream(q, nt, R, 100, 4096, [256] * B)
+            ss.begin(sp, ssc)
+            fl = 2.0 * 256 * 384 * R * B
+            if abl is not None:
+                os.environ["SIXDGS_DEBUG_ABLATE"] = str(abl)
+                note = f"select sweep k_logits_f16x<UB> under compile-time ablation {abl} (2 no epilogue, 18 no fragment reads + no epilogue, 11 no DMA + no epilogue, 27 MFMA + barriers, 59 MFMA only, 4096 idle-wave skip off)"
 
-                def one():
-                    ss.sweep(planes, scale, 0, None, update_norm=False)
-            else:
-                os.environ["SIXDGS_DEBUG_ABLATE"] = "59"
-                R2 = min(R, 16_000_000)
-                ws = torch.empty(ops.score_topk_workspace_bytes(R2, 2, 100), dtype=torch.uint8, device="cuda")
-                q2, nt2 = q[:2].contiguous(), nt[:2].contiguous()
-                fl = 2.0 * 256 * 384 * R2 * 2
-                note = "two-pass kernel, ablation 59 (MFMAs only), 2 images x 16 M rays; includes the second pass + top-k of garbage logits"
-
-                def one():
-                    ops.score_topk(q2, nt2, None, 100, want_scores=False, workspace=ws, key_planes=planes[:R2], key_scale=scale[:(R2 + 127) // 128], n_tok_host=[256, 256])
+            def one():
+                ss.sweep(planes, scale, 0, None, update_norm=False)
         elif wl == "chain":
             R = 8 << 20
             rays = syn.make_rays(1 << 20, 0)
