@@ -683,6 +683,16 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
         b0[t][pl] = read_b(t, 0, pl, 0);
       }
     wait_lds();
+    if (ABL & 16) {      // (ablation "no fragment reads": the second fragment set must still be DEFINED, or the compiler drops the MFMAs that use it --
+#pragma unroll          //  the r1-r4 "MFMA only" figures above 2.5 PFLOP/s came from that)
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          a1[t][pl] = a0[t][pl];
+          b1[t][pl] = b0[t][pl];
+          asm volatile("" : "+v"(a1[t][pl]), "+v"(b1[t][pl]));
+        }
+    }
 
     for (int tile = t_begin; tile < t_end; ++tile) {
       // after the last tile of the run the prefetch simply re-reads the current tile (harmless, keeps the slab loop and
@@ -1728,6 +1738,115 @@ __global__ void __launch_bounds__(1024) k_sel_emit(const int64_t* __restrict__ l
   }
 }
 
+// ---- short lists: the whole selection in ONE workgroup per image (round 4).  The k-th largest TILE maximum of U (r / 256 values: 75 k at 19 M rays,
+// 125 k at 32 M) and the top-100 of the <= 4096 re-scored candidates went through the same nine launches as a 32 M-element list (memset, 4 histogram
+// passes, count, scan, write, sort: ~215 us per selection at one image per step, where nothing overlaps them -- 0.43 ms of a 13.5 ms step).  Here: radix
+// select with the histogram in LDS (4 coalesced sweeps over the values, from L2), ONE ordered gather (a single workgroup walks the list in index order,
+// so the ranks are running counts: no count / scan / write split), bitonic sort.  Same definition as the multi-kernel path -- the k largest by (value
+// descending, index ascending) -- and the same bits (test_topk_small_lists_equal_the_multi_kernel_path).
+constexpr int64_t kTopkSmallMax = 1 << 17;
+__global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ scores, int64_t stride, int n, int topk, int k_eff,
+                                                      int64_t* __restrict__ idx, float* __restrict__ val, const int* __restrict__ only) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel[2];              // prefix of the k-th largest key decided so far, how many are still needed among the keys matching it
+  __shared__ unsigned sk[1024];
+  __shared__ long long si[1024];
+  __shared__ int wc[2][16];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (only != nullptr && only[b] == 0) return;
+  const float* s = scores + (int64_t)b * stride;
+  sk[t] = 0u;
+  si[t] = 0x7fffffffffffffffll;
+  unsigned prefix = 0u, remain = (unsigned)k_eff;
+  if (k_eff > 0) {
+    for (int p = 0; p < 4; ++p) {
+      if (t < 256) hist[t] = 0u;
+      __syncthreads();
+      const unsigned hi_mask = p == 0 ? 0u : (0xffffffffu << (32 - 8 * p));
+      const int shift = 24 - 8 * p;
+      for (int i = t; i < n; i += 1024) {
+        const unsigned key = score_key(s[i]);
+        if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (t < 64) {      // the digit of the k-th largest: lane l owns bins 255 - 4 l .. 252 - 4 l (descending), a wave scan finds the lane that crosses `remain`
+        unsigned c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = hist[255 - (4 * t + j)];
+        const unsigned loc = (c[0] + c[1]) + (c[2] + c[3]);
+        const unsigned inc = sdg_wave_inclusive_scan(loc), exc = inc - loc;
+        if (inc >= remain && exc < remain) {      // exactly one lane: the matching keys number at least `remain`
+          unsigned acc = exc, digit = 0u, rem = 0u;
+          bool found = false;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!found && acc + c[j] >= remain) { digit = (unsigned)(255 - (4 * t + j)); rem = remain - acc; found = true; }
+            acc += c[j];
+          }
+          sel[0] = prefix | (digit << shift);
+          sel[1] = rem;
+        }
+      }
+      __syncthreads();
+      prefix = sel[0];
+      remain = sel[1];
+    }
+    // ordered gather: keys above the threshold at their running rank, keys equal to it (in index order) behind them while `remain` lasts
+    const unsigned thr = prefix, n_greater = (unsigned)k_eff - remain;
+    unsigned run_g = 0u, run_e = 0u;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+      const int i = c0 + t;
+      unsigned key = 0u;
+      bool gt = false, eq = false;
+      if (i < n) {
+        key = score_key(s[i]);
+        gt = key > thr;
+        eq = key == thr;
+      }
+      const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+      if (lane == 0) { wc[0][wv] = __popcll(bg); wc[1][wv] = __popcll(be); }
+      __syncthreads();
+      unsigned og = 0u, oe = 0u, tg = 0u, te = 0u;
+#pragma unroll
+      for (int w2 = 0; w2 < 16; ++w2) {
+        const unsigned g = (unsigned)wc[0][w2], e = (unsigned)wc[1][w2];
+        if (w2 < wv) { og += g; oe += e; }
+        tg += g;
+        te += e;
+      }
+      __syncthreads();
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (gt) {
+        const unsigned pos = run_g + og + (unsigned)__popcll(bg & below);
+        if (pos < 1024u) { sk[pos] = key; si[pos] = (long long)i; }
+      } else if (eq) {
+        const unsigned re = run_e + oe + (unsigned)__popcll(be & below);
+        if (re < remain && n_greater + re < 1024u) { sk[n_greater + re] = key; si[n_greater + re] = (long long)i; }
+      }
+      run_g += tg;
+      run_e += te;
+      if (run_e >= remain && run_g >= n_greater) break;      // (uniform: everything wanted has been seen)
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      const int p = t ^ strd;
+      if (p > t) {
+        const bool up = (t & size) == 0;
+        const unsigned ka = sk[t], kb = sk[p];
+        const long long ia = si[t], ib = si[p];
+        const bool a_first = ka > kb || (ka == kb && ia < ib);
+        if (up ? !a_first : a_first) { sk[t] = kb; sk[p] = ka; si[t] = ib; si[p] = ia; }
+      }
+      __syncthreads();
+    }
+  if (t < topk) {
+    if (t < k_eff) { idx[(int64_t)b * topk + t] = si[t]; val[(int64_t)b * topk + t] = key_score(sk[t]); }
+    else { idx[(int64_t)b * topk + t] = -1; val[(int64_t)b * topk + t] = NAN; }
+  }
+}
+
 struct TopkPlan {
   int nb;          // gather blocks per image
   int64_t span;    // indices per gather block
@@ -1761,6 +1880,12 @@ int run_topk(const float* scores, int64_t stride, int64_t r, int batch, int topk
   unsigned* ckey = (unsigned*)(ws + p.off_ckey);
   int64_t* cidx = (int64_t*)(ws + p.off_cidx);
   const int k_eff = (int)(r < topk ? r : topk);
+  static const bool small_ok = getenv("SIXDGS_TOPK_SMALL") == nullptr || atoi(getenv("SIXDGS_TOPK_SMALL")) != 0;      // (=0: the multi-kernel path for every size; test hook)
+  if (small_ok && r <= kTopkSmallMax && topk <= 1024) {
+    hipLaunchKernelGGL(k_topk_small, dim3((unsigned)batch), dim3(1024), 0, s, scores, stride, (int)r, topk, k_eff, idx, val, only);
+    SDG_LAUNCH_OK();
+    return 0;
+  }
   if (k_eff > 0) {
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)batch * 4 * 256 * sizeof(unsigned), s);
     if (e != hipSuccess) return (int)e;

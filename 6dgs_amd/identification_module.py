@@ -259,9 +259,26 @@ class IdentificationModule(torch.nn.Module):
                     raise RuntimeError("6dgs_amd: the select workspace must exist before a hipGraph capture (run the batch once eagerly)")
                 self._select_ws = sw = None
                 self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
-            idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
-                                                max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
-                                                key_norm=kc["norm"])
+            # Token-aware launches (round 4): the sweep's waves work in rows of 64 tokens and skip the rows beyond an image's token count, but the
+            # images of ONE launch walk the key tiles in lock-step (sibling sets, they share every tile through L2) -- at the pace of the image
+            # with the most rows.  Masked views differ (Tanks&Temples: 80-176 of 256 tokens), so a batch goes as one launch per ROW-COUNT CLASS:
+            # the images are taken in descending class order and the results put back (a few hundred bytes per image).
+            rows_of = [(int(v) + 63) // 64 for v in n_host]
+            order = sorted(range(b), key=lambda i: -rows_of[i])
+            cuts = [0] + [j for j in range(1, b) if rows_of[order[j]] != rows_of[order[j - 1]]] + [b]
+            if len(cuts) == 2:
+                idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
+                                                    max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
+                                                    key_norm=kc["norm"])
+            else:
+                perm = torch.tensor(order, dtype=torch.int64, device=q.device)
+                q_s, n_s = q.index_select(0, perm), n_tok.index_select(0, perm)
+                parts = [ops.score_select(q_s[c0:c1], n_s[c0:c1], kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
+                                          max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile,
+                                          n_tok_host=[n_host[i] for i in order[c0:c1]], key_norm=kc["norm"]) for c0, c1 in zip(cuts[:-1], cuts[1:])]
+                cat = [torch.cat([p[j] for p in parts]) for j in range(3)]                   # sorted position i holds image order[i]
+                idx, val, status = (torch.empty_like(c).index_copy_(0, perm, c) for c in cat)
+            self.last_select_launch_classes = [rows_of[order[c]] for c in cuts[:-1]]
             self.last_scoring_path = "select"
             pend = dict(status=status, q=q, n_tok=n_tok, k=rays_to_output, workspace=workspace, images_in_flight=images_in_flight,
                         rays=(rays_ori, rays_dir, rays_rgb))

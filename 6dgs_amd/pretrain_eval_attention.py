@@ -166,8 +166,10 @@ def main(argv=None, backbone: Optional[torch.nn.Module] = None) -> List[dict]:
         raise RuntimeError("6dgs_amd: the evaluation sweep needs an MI355X (no CPU fallback on the product path)")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    if dd.is_dist() and rank == 0:
-        print(f"[6dgs_amd] evaluation sweep over {dd.ranks_seen(torch.device(device))} rank(s), backend {dd.backend_name()}")
+    if dd.is_dist():
+        seen = dd.ranks_seen(torch.device(device))          # a collective: every rank takes part, rank 0 reports
+        if rank == 0:
+            print(f"[6dgs_amd] evaluation sweep over {seen} rank(s), backend {dd.backend_name()}")
     results: List[dict] = []
     for exp in parse_exp_dir(args.exp_path, PREFIXES.get(args.data_type, "")).values():
         ckpt_args = get_checkpoint_arguments(exp["exp_dir_filepath"])

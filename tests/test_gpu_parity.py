@@ -541,11 +541,11 @@ def test_solve_pose_batched_equals_single(ops, golden):
 
 
 def test_topk_randomised_against_the_oracle(ops, oracle):
-    """Radix select + ordered gather + bitonic sort against the oracle's (value desc, index asc) rule on 40 random shapes:
+    """Radix select + ordered gather + bitonic sort against the oracle's (value desc, index asc) rule on 60 random shapes:
     heavy ties, all-equal rows, +-inf, signed zeros, sizes around the block / pass boundaries, k from 1 to 1024."""
     rng = np.random.default_rng(2024)
-    for trial in range(40):
-        r = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 65537, 300001]))
+    for trial in range(60):
+        r = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 65537, 131072, 131073, 300001]))      # <= 2^17: the one-workgroup kernel (k_topk_small); beyond: the multi-kernel path
         k = int(rng.choice([1, 7, 100, 256, 1024]))
         kind = trial % 5
         if kind == 0:
@@ -758,3 +758,36 @@ def test_chain_layouts_give_identical_keys(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
     assert "CM_CHECK PASS" in p.stdout
+
+
+def test_topk_small_lists_equal_the_multi_kernel_path(tmp_path):
+    """Round 4: lists of <= 2^17 values are selected by ONE workgroup per image (k_topk_small) instead of nine launches.  Same definition, same
+    bits: the tool runs both paths (SIXDGS_TOPK_SMALL=0 forces the multi-kernel one; read once per process) on lists with heavy ties, all-equal rows,
+    infinities and sizes around 1024 / 2^17, and compares idx and val exactly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import importlib, sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "ops = importlib.import_module('6dgs_amd.ops')\n"
+        "rng = np.random.default_rng(77); out = {}\n"
+        "for r in (1, 37, 100, 101, 1023, 1024, 1025, 4096, 75000, 131071, 131072):\n"
+        "    for kind in range(4):\n"
+        "        s = [rng.standard_normal((3, r)), rng.integers(-2, 3, size=(3, r)).astype(np.float64), np.full((3, r), -1.5), rng.standard_normal((3, r)) * 1e-3][kind].astype(np.float32)\n"
+        "        if kind == 0 and r > 40: s[0, 17] = np.inf; s[1, 33] = -np.inf\n"
+        "        for k in (1, 100, 1024):\n"
+        "            i, v = ops.topk(torch.from_numpy(s).cuda(), k)\n"
+        "            out[f'{r}_{kind}_{k}'] = (i.cpu(), v.cpu())\n"
+        "torch.save(out, sys.argv[1])\n" % root)
+    files = []
+    for mode in ("1", "0"):
+        f = str(tmp_path / f"topk_{mode}.pt")
+        p = subprocess.run([sys.executable, "-W", "ignore", "-c", prog, f], env=dict(os.environ, SIXDGS_TOPK_SMALL=mode), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        files.append(torch.load(f))
+    a, b = files
+    assert a.keys() == b.keys() and len(a) == 11 * 4 * 3
+    for key in a:
+        assert torch.equal(a[key][0], b[key][0]), key
+        assert torch.equal(torch.nan_to_num(a[key][1], nan=-7.0), torch.nan_to_num(b[key][1], nan=-7.0)), key
