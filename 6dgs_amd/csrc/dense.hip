@@ -660,7 +660,6 @@ __global__ void __launch_bounds__(256) k_weight_planes(const float* __restrict__
   *reinterpret_cast<f16x8_t*>(d + 64) = l;
 }
 
-bool g_dense_no_split = getenv("SIXDGS_DENSE_NO_SPLIT") != nullptr;      // developer switch: the round-2 form (both passes in one workgroup)
 // The chain's activation layout of this process: chunk-major unless SIXDGS_DENSE_CM=0 (ray-major, rounds 2-3).  One per process, because the
 // weight planes are packed once (sixdgs_pack_scorer_weights) with or without the row permutation that goes with it.  Both layouts give the
 // same keys bit for bit (same MFMA order per output, same scales; tools/cm_check.py, test_chain_layouts_give_identical_keys); chunk-major is
@@ -692,7 +691,7 @@ int launch_dense(const DenseArgs& A, hipStream_t s) {
   const int64_t tiles = sdg_cdiv(A.m, wide ? 128 : 256);
   if (tiles > 0x7fffffffLL) return SIXDGS_E_BADARG;
   const unsigned n_pass = (unsigned)(wide ? A.n / 384 : A.n / 256);
-  const unsigned split = (!wide && n_pass == 2 && !g_dense_no_split) ? 1u : 0u;
+  const unsigned split = (!wide && n_pass == 2) ? 1u : 0u;      // (round 2 ran both passes in one workgroup: the N = 512 layers read their input twice)
   int grid = dense_grid(split ? 2 * tiles : tiles);
   if (grid <= 0) return (int)hipErrorInvalidDevice;
   if (split) grid &= ~1;                       // sibling pairs

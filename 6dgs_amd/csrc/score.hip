@@ -538,7 +538,7 @@ constexpr int kBNX = 256;                // rays per tile
 constexpr int kSiblingSyncDefault = 1;
 constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
 constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
-constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1; SIXDGS_SIB_PERIOD overrides)
+constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
 // for that token in this tile).  0.766 x the bytes of fp32 logits, written once and read once per image.
@@ -2398,10 +2398,7 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
       V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
       V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
       V.sib_extra = sibling_sync_mode() == 3 ? 1u : 0u;
-      {
-        static const int period = [] { const char* e = getenv("SIXDGS_SIB_PERIOD"); const int v = e ? atoi(e) : kSibPeriod; return v >= 1 ? v : 1; }();
-        V.sib_period = period;
-      }
+      V.sib_period = kSibPeriod;
       if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
       grid = (unsigned)(V.n_sets * batch);
     }

@@ -409,6 +409,9 @@ def main():
                                             if path.startswith("streamed select") else "twice (row statistics, then scores + top-k merge)")
                                          + "; nothing of size R x 384 is resident")
     out["config"]["scoring_path"] = path
+    tk = sol.get("tokens") if isinstance(sol, dict) else None
+    if tk is not None:      # tokens that survive the wrapper's mask per image of the last step (256 for RGB queries): the roofline credits 2*T*384 FLOP per ray with THESE counts
+        out["config"]["tokens_per_image"] = [int(tk[i].shape[0]) for i in range(len(tk))]
     if cand is not None:
         out["config"]["select_candidates_last_batch"] = cand
     if l24 is not None:

@@ -389,13 +389,14 @@ def test_sibling_meeting_gives_up_on_a_member_that_never_arrives(ops, tmp_path):
     like -- and must release itself after the limit and return the same result, in bounded time."""
     import subprocess
     outs = {}
-    for mode in ("3", "0"):
+    for mode in ("3", "0", "2"):
         f = str(tmp_path / f"m{mode}.npz")
         env = dict(os.environ, SIXDGS_SIBLING_SYNC=mode, SIXDGS_TEST_ROOT=ROOT)
         p = subprocess.run([sys.executable, "-W", "ignore", "-c", _CHILD, f], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         outs[mode] = np.load(f)
     a, b = outs["3"], outs["0"]
+    assert np.array_equal(outs["2"]["idx"], b["idx"]) and np.array_equal(outs["2"]["val"], b["val"]) and np.array_equal(outs["2"]["status"], b["status"])      # persistent sets without the meeting: the same bits as the one-shot grid
     assert (a["status"] >= 0).all() and np.array_equal(a["status"] >= 0, b["status"] >= 0)
     assert np.array_equal(a["idx"], b["idx"]) and np.allclose(a["val"], b["val"], rtol=1e-6, atol=0)
     assert float(a["seconds"]) < 2.0, float(a["seconds"])          # 64 sets give up once each, concurrently: tens of milliseconds
