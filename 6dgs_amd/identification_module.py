@@ -266,7 +266,7 @@ class IdentificationModule(torch.nn.Module):
             rows_of = [(int(v) + 63) // 64 for v in n_host]
             order = sorted(range(b), key=lambda i: -rows_of[i])
             cuts = [0] + [j for j in range(1, b) if rows_of[order[j]] != rows_of[order[j - 1]]] + [b]
-            if len(cuts) == 2:
+            if len(cuts) == 2 or capturing:      # (inside a hipGraph capture the permutation's H2D copy is not allowed: one launch, lock-step pace)
                 idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
                                                     max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
                                                     key_norm=kc["norm"])

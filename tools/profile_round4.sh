@@ -24,7 +24,7 @@ vals=[float(r["Counter_Value"]) for r in rows]
 n=len(vals)//5
 for l in range(5):
     v=vals[l::5][n//2:]
-    print("$C layer", l+1, "mean raw KB per launch of 262144 rays", sum(v)/len(v), "launches", len(v))
+    print("$C layer", l+1, "mean raw KB per launch of 1048576 rays (tools/time_keys.py 1048576: one chunk)", sum(v)/len(v), "launches", len(v))
 PY
   rm -rf $O/pmck_$C
 done
