@@ -538,6 +538,7 @@ constexpr int kBNX = 256;                // rays per tile
 constexpr int kSiblingSyncDefault = 1;
 constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
 constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
+constexpr int kSweepMaxImages = 8;      // images per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  0 / SIXDGS_SWEEP_MAX_IMAGES=0: no cap
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
@@ -1764,9 +1765,26 @@ __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ s
       __syncthreads();
       const unsigned hi_mask = p == 0 ? 0u : (0xffffffffu << (32 - 8 * p));
       const int shift = 24 - 8 * p;
-      for (int i = t; i < n; i += 1024) {
-        const unsigned key = score_key(s[i]);
-        if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      // The first passes see (nearly) ONE digit for every element -- scores of one image share their sign and leading exponent bits -- and 64 lanes
+      // adding to one LDS word serialise (the first build spent 160 us per call on exactly that, profiles/r04_bench_headline_kernel_trace.md): the lanes
+      // that share the first active lane's digit are counted with a ballot and added once; the others (later passes: few, scattered) add for themselves.
+      for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + t;
+        unsigned key = 0u;
+        bool act = false;
+        if (i < n) {
+          key = score_key(s[i]);
+          act = (key & hi_mask) == prefix;
+        }
+        const unsigned bin = (key >> shift) & 255u;
+        const unsigned long long m = __ballot(act);
+        if (m != 0ull) {
+          const int leader = __ffsll((long long)m) - 1;
+          const unsigned lb = (unsigned)__shfl((int)bin, leader);
+          const unsigned long long same = __ballot(act && bin == lb);
+          if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+          else if (act && bin != lb) atomicAdd(&hist[bin], 1u);
+        }
       }
       __syncthreads();
       if (t < 64) {      // the digit of the k-th largest: lane l owns bins 255 - 4 l .. 252 - 4 l (descending), a wave scan finds the lane that crosses `remain`
@@ -2378,6 +2396,27 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && ctok && gsum && u && ws && ((uintptr_t)key_planes % 16) == 0 &&
                 ((uintptr_t)q % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)ws % 256) == 0);
+  // Images per launch are capped (round 4): every sibling streams its OWN q planes (393 KB per image) once per tile, and the images of a launch share an
+  // XCD's 4 MB L2 with the key tiles in flight -- with many images the q planes fall out of it.  Measured (tools/time_sweep.py B 8388608,
+  // profiles/r04_sweep_images_per_launch.log; TFLOP/s fp32-equivalent): one launch for the whole batch 415 / 422 / 413 / 401 / 354 / 278 at 4 / 8 / 12 / 16 / 24 /
+  // 32 images; launches of 8: 423 / 424 / 426 at 16 / 24 / 32.  So a batch goes in launches of kSweepMaxImages, the last one taking what is left up to
+  // kSweepMaxTail (a launch of one or two images would pull every key tile from HBM for itself: 0.455).  Every launch streams the key planes once, i.e.
+  // 1/8 of a sweep's bytes per image; results do not depend on the grouping (batch invariance: tests/test_gpu_full_size.py, test_gpu_select.py).
+  {
+    static const int cap = [] { const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES"); const int v = e ? atoi(e) : kSweepMaxImages; return v; }();
+    const int tail = cap + cap / 2;
+    if (cap > 0 && batch > tail) {
+      for (int b0 = 0; b0 < batch;) {
+        const int left = batch - b0, nb = left > tail ? cap : left;
+        const int st = sixdgs_select_sweep(q + (int64_t)b0 * kT * SIXDGS_D, d_n_tok + b0, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r,
+                                           ctok + (int64_t)b0 * kT, gsum + (int64_t)b0 * kT, u + (int64_t)b0 * u_stride, u_stride,
+                                           u_tile_max ? u_tile_max + (int64_t)b0 * (u_stride / 256) : nullptr, ws, ws_bytes, stream, prof);
+        if (st) return st;
+        b0 += nb;
+      }
+      return 0;
+    }
+  }
   hipStream_t s = sdg_stream(stream);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;

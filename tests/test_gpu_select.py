@@ -403,3 +403,31 @@ def test_sibling_meeting_gives_up_on_a_member_that_never_arrives(ops, tmp_path):
     c = make_case(ops, 300_000, 77, 6.0, [256, 200, 256, 31])      # and the default layout (lock-step, everyone arrives) in this process
     idx, val, st = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=4096)
     assert np.array_equal(idx.cpu().numpy(), b["idx"])
+
+
+def test_sweep_launch_grouping_is_invisible(ops, tmp_path):
+    """Round 4: a batch of more than 12 images is swept in launches of 8 (the images of a launch share an XCD's L2; `sixdgs_select_sweep`).  The grouping must not
+    show: 14 images (launches of 8 + 6; ragged token counts) give the same idx / val / status bit for bit as ONE launch of 14 (SIXDGS_SWEEP_MAX_IMAGES=0) and as
+    launches of 4 -- and each image the same as alone."""
+    import subprocess
+    child = _CHILD.replace("[256, 200, 256, 31]", "[256, 200, 256, 31, 256, 137, 256, 256, 64, 256, 1, 256, 190, 256]")
+    outs = {}
+    for cap in ("", "0", "4"):
+        f = str(tmp_path / f"cap{cap or 'default'}.npz")
+        env = dict(os.environ, SIXDGS_TEST_ROOT=ROOT)
+        env.pop("SIXDGS_SWEEP_MAX_IMAGES", None)
+        if cap:
+            env["SIXDGS_SWEEP_MAX_IMAGES"] = cap
+        p = subprocess.run([sys.executable, "-W", "ignore", "-c", child, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[cap] = np.load(f)
+    a = outs[""]
+    assert a["idx"].shape == (14, 100) and (a["status"][[0, 1, 2, 4]] >= 100).all()
+    for cap in ("0", "4"):
+        b = outs[cap]
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["status"], b["status"]), cap
+        assert np.array_equal(np.nan_to_num(a["val"], nan=-7.0), np.nan_to_num(b["val"], nan=-7.0)), cap
+    c = make_case(ops, 300_000, 77, 6.0, [256, 200, 256, 31, 256, 137, 256, 256, 64, 256, 1, 256, 190, 256])
+    for i in (1, 9, 13):
+        idx, val, st = ops.score_select(c["q"][i:i + 1].contiguous(), c["nt"][i:i + 1].contiguous(), c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=4096)
+        assert np.array_equal(idx.cpu().numpy()[0], a["idx"][i]) and int(st[0]) == int(a["status"][i])
