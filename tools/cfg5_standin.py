@@ -78,8 +78,7 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
             ori, dr, rgb = ori[fin].contiguous(), dr[fin].contiguous(), rgb[fin].contiguous()
         del fin, scene
         R = int(ori.shape[0])
-        idm.invalidate_caches()
-        torch.cuda.empty_cache()
+        idm.invalidate_caches()      # (no torch.cuda.empty_cache() between scenes: handing 100-200 GB back to the driver makes the NEXT scene's hipMallocs pay for
         resident = R * 1536 + ops.ray_keys_workspace_bytes(R, ops.RAY_KEYS_CHUNK_MIN) + 24 * R * 16 < 0.85 * hbm
         kprof = ops.KernelProfile()
         if resident:
@@ -100,8 +99,11 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         # ---- the timed part: all test views of the scene, batch by batch, poses on the host at the end of every batch
         prof = ops.KernelProfile()
         tok_counts, first = [], None
+        mem0 = (round(torch.cuda.memory_allocated(dev) / 2**30, 1), round(torch.cuda.memory_reserved(dev) / 2**30, 1), round(torch.cuda.mem_get_info(dev)[0] / 2**30, 1))
+        step_s = []
         t0 = time.perf_counter()
         for b0 in range(0, len(images), batch):
+            t_b = time.perf_counter()
             sol = tp.estimate_poses(idm, images[b0:b0 + batch], ori, dr, rgb, gt_c2w=gts[b0:b0 + batch], profile=prof,
                                     streamed_chunk_rays=None if resident else args.chunk_rays, defer_status=resident)
             if "packed" in sol:
@@ -112,6 +114,8 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
             tok_counts += [int(tk[i].shape[0]) for i in range(len(tk))]
             if first is None:
                 first = {"tokens": tk[0].contiguous().clone(), "up": sol["up"][:1].clone(), "c2w": c2w[0].clone()}
+            step_s.append(round(time.perf_counter() - t_b, 3))
+            del sol
         torch.cuda.synchronize()
         dd.barrier()
         t_eval = dd.max_over_ranks(time.perf_counter() - t0, dev)
@@ -122,7 +126,8 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
                "scoring_path": path, "images_per_step": batch, "tokens_per_image_mean": round(float(np.mean(tok_counts)), 1) if tok_counts else None,
                "tokens_per_image_min_max": [int(min(tok_counts)), int(max(tok_counts))] if tok_counts else None,
                "setup_s": round(t_setup, 2), "ray_mlp_keys_tflops": round(k_fl / (k_ms * 1e-3) / 1e12, 1) if k_ms > 0 else None,
-               "eval_s": round(t_eval, 3), "poses_per_s": round(n_views / t_eval, 3),
+               "eval_s": round(t_eval, 3), "poses_per_s": round(n_views / t_eval, 3), "step_s": step_s,
+               "gib_allocated_reserved_free_before_eval": mem0,
                "sweep_tflops": round(l_fl / (l_ms * 1e-3) / 1e12, 1) if l_ms > 0 else None}
         # ---- one view of the scene against the oracle, on a prefix of its rays (rank 0)
         if rank == 0 and first is not None and not args.skip_cpu_baseline:
@@ -158,7 +163,6 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         tot_views, tot_eval, tot_setup = tot_views + n_views, tot_eval + t_eval, tot_setup + t_setup
         del ori, dr, rgb, images, gts
         idm.invalidate_caches()
-        torch.cuda.empty_cache()
     ok = [r["parity_vs_oracle"] for r in rows if "parity_vs_oracle" in r]
     out = {
         "metric": "poses/sec", "value": round(tot_views / tot_eval, 4), "unit": "poses/s", "n_gpus": world, "steps": len(rows), "warmup": 0,
