@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "lib6dgs_hip.so")
 HOSTCHECK = os.path.join(CSRC, "libsixdgs_hostcheck.so")
 SOURCES = ["geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip"]
-HEADERS = ["common.h", "device_math.h", "gemm_kernel.h", "dense.h", os.path.join("..", "..", "include", "sixdgs.h"), "dense_layout.h"]
+HEADERS = ["common.h", "device_math.h", "gemm_kernel.h", "dense.h", os.path.join("..", "..", "include", "sixdgs.h"), "dense_layout.h", "sweep_plan.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("SIXDGS_EXTRA_FLAGS", "").split()       # developer builds (e.g. -DSDG_DENSE_PROF: tools/prof_dense.py)
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 def build_hostcheck(force: bool = False) -> str:
     """Host instantiation of device_math.h and dense_layout.h for the CPU test-suite (no GPU code inside)."""
     src = os.path.join(CSRC, "hostcheck.cpp")
-    deps = [src, os.path.join(CSRC, "device_math.h"), os.path.join(CSRC, "dense_layout.h")]
+    deps = [src, os.path.join(CSRC, "device_math.h"), os.path.join(CSRC, "dense_layout.h"), os.path.join(CSRC, "sweep_plan.h")]
     if force or _stale(HOSTCHECK, deps):
         cmd = [HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", src,
                "-o", HOSTCHECK]

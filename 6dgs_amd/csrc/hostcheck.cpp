@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "device_math.h"
+#include "sweep_plan.h"
 #include "dense_layout.h"
 using namespace sdg;
 
@@ -136,6 +137,7 @@ unsigned hc_dl_load_chunk8(int chunk_major, unsigned tid) { return dl::load_chun
 unsigned hc_dl_cm_src_offset(unsigned ray_in_tile, unsigned chunk8, unsigned granule_stride) {
   return dl::cm_src_offset(ray_in_tile, chunk8 * (unsigned)dl::kChunkRun, granule_stride);
 }
+int hc_sweep_launch_images(int left, int cap) { return sdg::sweep_launch_images(left, cap); }
 int hc_dl_const(int which) {
   const int v[] = {dl::kSlabB, dl::kPRow, dl::kGran, dl::kGranSlab, dl::kChunkRun};
   return which >= 0 && which < 5 ? v[which] : -1;

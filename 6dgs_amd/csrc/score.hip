@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include "gemm_kernel.h"
+#include "sweep_plan.h"
 
 using namespace sdg;
 
@@ -2404,10 +2405,9 @@ int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h
   // 1/8 of a sweep's bytes per image; results do not depend on the grouping (batch invariance: tests/test_gpu_full_size.py, test_gpu_select.py).
   {
     static const int cap = [] { const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES"); const int v = e ? atoi(e) : kSweepMaxImages; return v; }();
-    const int tail = cap + cap / 2;
-    if (cap > 0 && batch > tail) {
+    if (sweep_launch_images(batch, cap) < batch) {
       for (int b0 = 0; b0 < batch;) {
-        const int left = batch - b0, nb = left > tail ? cap : left;
+        const int nb = sweep_launch_images(batch - b0, cap);
         const int st = sixdgs_select_sweep(q + (int64_t)b0 * kT * SIXDGS_D, d_n_tok + b0, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r,
                                            ctok + (int64_t)b0 * kT, gsum + (int64_t)b0 * kT, u + (int64_t)b0 * u_stride, u_stride,
                                            u_tile_max ? u_tile_max + (int64_t)b0 * (u_stride / 256) : nullptr, ws, ws_bytes, stream, prof);

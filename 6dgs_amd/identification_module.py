@@ -28,6 +28,17 @@ def _lib_ray_keys_ws(r: int, max_chunk: int = ops.RAY_KEYS_CHUNK) -> int:
     return int(_lib.load().sixdgs_ray_keys_workspace_bytes(int(r), int(max_chunk)))
 
 
+def launch_classes(n_tok_host):
+    """Images of a batch grouped for the token-aware sweep: -> (rows_of [B]: 64-token wave rows image i needs, order: the images in descending row count
+    (stable: ties keep the caller's order), cuts: boundaries in `order` between two row-count classes, starting with 0 and ending with B).  The images of
+    one launch walk the key tiles in lock-step at the pace of the image with the most rows, so each class gets its own launch."""
+    rows_of = [(int(v) + 63) // 64 for v in n_tok_host]
+    b = len(rows_of)
+    order = sorted(range(b), key=lambda i: -rows_of[i])
+    cuts = [0] + [j for j in range(1, b) if rows_of[order[j]] != rows_of[order[j - 1]]] + [b]
+    return rows_of, order, cuts
+
+
 class RayPreprocessor(torch.nn.Module):
     """Parameter holder with the reference layout (ray_preprocessor.py:11-34)."""
 
@@ -263,9 +274,7 @@ class IdentificationModule(torch.nn.Module):
             # images of ONE launch walk the key tiles in lock-step (sibling sets, they share every tile through L2) -- at the pace of the image
             # with the most rows.  Masked views differ (Tanks&Temples: 80-176 of 256 tokens), so a batch goes as one launch per ROW-COUNT CLASS:
             # the images are taken in descending class order and the results put back (a few hundred bytes per image).
-            rows_of = [(int(v) + 63) // 64 for v in n_host]
-            order = sorted(range(b), key=lambda i: -rows_of[i])
-            cuts = [0] + [j for j in range(1, b) if rows_of[order[j]] != rows_of[order[j - 1]]] + [b]
+            rows_of, order, cuts = launch_classes(n_host)
             if len(cuts) == 2 or capturing:      # (inside a hipGraph capture the permutation's H2D copy is not allowed: one launch, lock-step pace)
                 idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
                                                     max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
