@@ -78,7 +78,8 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
             ori, dr, rgb = ori[fin].contiguous(), dr[fin].contiguous(), rgb[fin].contiguous()
         del fin, scene
         R = int(ori.shape[0])
-        idm.invalidate_caches()      # (no torch.cuda.empty_cache() between scenes: handing 100-200 GB back to the driver makes the NEXT scene's hipMallocs pay for
+        idm.invalidate_caches()
+        torch.cuda.empty_cache()
         resident = R * 1536 + ops.ray_keys_workspace_bytes(R, ops.RAY_KEYS_CHUNK_MIN) + 24 * R * 16 < 0.85 * hbm
         kprof = ops.KernelProfile()
         if resident:
@@ -91,6 +92,16 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         images = [torch.from_numpy(c["image"]).to(dev) for c in cams]
         gts = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams]).to(dev) if cams else None
         batch = max(1, min(len(images), args.batch if resident else args.streamed_batch))
+        if not resident and images:
+            # A streamed scene's buffers -- U (4 B per ray and image), one chunk's key planes and chain workspace -- are allocated inside the step.  Their first
+            # hipMalloc is scene set-up like the resident scenes' plane buffer, and it is NOT cheap behind a scene that just returned 200 GB to the driver: the
+            # pages are cleared on the way back out (measured: the same streamed step 5.1 s on its own, 8.1 s behind a resident scene).  Touch them here once.
+            n_c = min(args.chunk_rays, R)
+            warm = [torch.empty(batch * ((R + 255) // 256 * 256) * 4, dtype=torch.uint8, device=dev), torch.empty(n_c * 1536, dtype=torch.uint8, device=dev),
+                    torch.empty(ops.ray_keys_workspace_bytes(n_c), dtype=torch.uint8, device=dev)]
+            for w_ in warm:
+                w_[:: 1 << 20].zero_()
+            del warm, w_
         if resident and images:      # scene set-up, like the key planes: the first batch once untimed, so that the select workspace (20 B per ray and image:
             tp.estimate_poses(idm, images[:batch], ori, dr, rgb, gt_c2w=gts[:batch], defer_status=True)      # a 10-40 GB hipMalloc at ~50 GB/s) and the image-side graph exist
         torch.cuda.synchronize()
@@ -163,6 +174,8 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         tot_views, tot_eval, tot_setup = tot_views + n_views, tot_eval + t_eval, tot_setup + t_setup
         del ori, dr, rgb, images, gts
         idm.invalidate_caches()
+        torch.cuda.empty_cache()      # (a 100-200 GB plane buffer left in the caching allocator gets split by small tensors and can then neither be reused for the next
+                                      #  scene's planes nor released: out of memory on the fourth scene when this call was left out)
     ok = [r["parity_vs_oracle"] for r in rows if "parity_vs_oracle" in r]
     out = {
         "metric": "poses/sec", "value": round(tot_views / tot_eval, 4), "unit": "poses/s", "n_gpus": world, "steps": len(rows), "warmup": 0,
