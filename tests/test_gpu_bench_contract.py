@@ -47,6 +47,7 @@ def test_bench_single_gpu_json_contract():
     assert "error" not in p, p
     assert p["sample_rays"] == 100000 and p["top100_identical"] is True and p["score_rel_err"] < 1e-5
     assert p["two_pass"]["value_rel_err"] < 1e-5 and p["select"]["value_rel_err"] < 1e-5 and p["select"]["top100_identical"] is True
+    assert p["ray_mlp_keys"]["max_row_rel_err"] < 5e-6 and p["ray_mlp_keys"]["rays"] > 0 and "every 5-th ray" in p["sample"]      # round 4: strided sample, the oracle's own keys
     assert p["rot_err_deg"] < 1e-2 and p["trans_err"] < 1e-4 * max(1.0, abs(p["pose"]["vs_synthetic_gt"]["oracle"]["trans_err"]))
     g = p["pose"]["vs_synthetic_gt"]
     assert abs(g["hip"]["rot_err_deg"] - g["oracle"]["rot_err_deg"]) < 1e-2 and abs(g["hip"]["trans_err"] - g["oracle"]["trans_err"]) < 1e-3
