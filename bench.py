@@ -388,6 +388,8 @@ def main():
                          + "; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
             "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R_total, "images_per_gpu_per_step": args.batch,
             "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
+            # select path: the library sweeps a batch of more than 12 images in launches of 8 (csrc/sweep_plan.h; SIXDGS_SWEEP_MAX_IMAGES)
+            "images_per_select_sweep_launch": (args.batch if args.batch <= 12 else 8),
             "parallelism": (f"ray-sharded x{world} (scene broadcast over RCCL, every rank emits and keeps the key planes of its block of ellipsoids: "
                             f"{R} of {R_total} rays on rank 0; per batch a few KB of all-reduce / all-gather: sample statistics, g_t, U_(k), candidates)"
                             if ray_sharded else f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)"),
