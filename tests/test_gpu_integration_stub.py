@@ -6,7 +6,6 @@ import importlib
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 

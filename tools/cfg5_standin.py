@@ -14,9 +14,6 @@ softmax scorer, top-100 and pose solve against the HIP path on the same prefix a
 oracle 6-9 minutes per view.
 
 Multi-rank: like the evaluation sweep every rank builds every scene and takes a contiguous block of its test views."""
-import importlib
-import json
-import os
 import time
 
 import numpy as np
