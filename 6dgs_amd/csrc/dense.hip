@@ -19,9 +19,6 @@
 #include "device_math.h"
 #include "dense.h"
 #include "dense_layout.h"
-#ifndef SDG_FRAG_ORDER
-#define SDG_FRAG_ORDER 0
-#endif
 #include <cstdlib>
 
 using namespace sdg;
@@ -285,16 +282,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
       f16x8_t a[NTM][2], b[NTN][2];
 #pragma unroll
       for (int kstep = 0; kstep < 2; ++kstep) {
-#if SDG_FRAG_ORDER      // (round-4 A/B, profiles/r04_chain_lds_dma_ab.log: the planes the first term l*h needs first -- 305.9 / 304.8 vs 301.9 / 305.7 TFLOP/s: no difference; not the default)
-#pragma unroll
-        for (int t = 0; t < NTM; ++t) a[t][1] = *reinterpret_cast<const f16x8_t*>(sw + t * 128 * kPRow + 64 + kstep * 32);
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) b[t][0] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + kstep * 32);
-#pragma unroll
-        for (int t = 0; t < NTM; ++t) a[t][0] = *reinterpret_cast<const f16x8_t*>(sw + t * 128 * kPRow + kstep * 32);
-#pragma unroll
-        for (int t = 0; t < NTN; ++t) b[t][1] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + 64 + kstep * 32);
-#else
+        // (fragment reads in plane order; reading the planes of the first term l*h first was measured in round 4 -- 305.9 / 304.8 vs 301.9 / 305.7 TFLOP/s,
+        //  profiles/r04_chain_lds_dma_ab.log: no difference -- and dropped)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -302,7 +291,6 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
 #pragma unroll
           for (int t = 0; t < NTN; ++t) b[t][pl] = *reinterpret_cast<const f16x8_t*>(sr + t * 32 * kPRow + pl * 64 + kstep * 32);
         }
-#endif
         // (weight plane, ray plane): l*h, h*l, h*h -- smallest magnitude first
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) {
