@@ -22,7 +22,7 @@ sz = C.c_size_t
 
 
 PROFILE_SLOTS = 128
-ABI_VERSION = 4          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
+ABI_VERSION = 5          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
 
 
 class Profile(C.Structure):
@@ -31,7 +31,7 @@ class Profile(C.Structure):
 
 
 class ScorerWeights(C.Structure):
-    _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wk", "bk", "wq", "bq", "m1", "m2", "m3", "m4", "mk", "planes")]
+    _fields_ = [(n, vp) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "wk", "bk", "wq", "bq", "m1", "m2", "m3", "m4", "mk", "w4k", "b4k", "m4k", "planes")]
 
 
 # name -> (restype, argtypes); mirrors include/sixdgs.h one to one

@@ -707,13 +707,22 @@ extern "C" int sixdgs_debug_dense_prof(long long* out) { return (int)hipMemcpyFr
 
 namespace sdg {
 
-size_t dense_weight_plane_bytes() { return (size_t)(512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12) * kSlabB; }
+size_t dense_weight_plane_bytes() { return (size_t)(512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12 + 384 * 16) * kSlabB; }
+
+// k_proj folded into layer 4 (round 5): layer 4 has no non-linearity behind it (ray_preprocessor.py:27-31,46) and k_proj follows
+// (our_multihead_attention.py:74), so K = (Wk W4) h3 + (Wk b4 + bk) -- four launches per chunk instead of five, 294 912 of the 2 025 472
+// FLOP per ray and the 3.1 KB/ray round trip of layer 4's planes gone.  The composite weights come from sixdgs_pack_weights (fp64 composition,
+// one rounding).  On unless SIXDGS_FOLD_KPROJ=0 (read at every call: the five-layer form stays reachable for A/B runs and the parity test).
+bool dense_fold_kproj() {
+  const char* e = getenv("SIXDGS_FOLD_KPROJ");
+  return e ? atoi(e) != 0 : true;
+}
 
 int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipStream_t s) {
   struct L { const float* src; int n; int64_t ld; int c0, kcols, kslabs; const float* wmax; int ks_total, s_off; size_t off; int perm; };
   const int pm = dense_chunk_major() ? 1 : 0;      // the layers that WRITE chunk-major planes (all but k_proj) have their rows permuted
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
-               ok = o4 + (size_t)384 * 16 * kSlabB;
+               ok = o4 + (size_t)384 * 16 * kSlabB, o4k = ok + (size_t)384 * 12 * kSlabB;
   const L layers[] = {
       {w->w1, 512, SIXDGS_RAY_IN_PAD, 0, SIXDGS_RAY_IN_PAD, 5, w->m1, 5, 0, o1, pm},
       {w->w2, 512, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m2, 16, 0, o2, pm},
@@ -721,6 +730,7 @@ int dense_pack_weight_planes(const sixdgs_scorer_weights* w, char* planes, hipSt
       {w->w3, 512, SIXDGS_HID + SIXDGS_RAY_IN_PAD, SIXDGS_HID, SIXDGS_RAY_IN_PAD, 5, w->m3, 21, 16, o3, pm},     // ... then the x columns, padded to 5 slabs
       {w->w4, 384, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m4, 16, 0, o4, pm},
       {w->wk, 384, SIXDGS_D, 0, SIXDGS_D, 12, w->mk, 12, 0, ok, 0},
+      {w->w4k, 384, SIXDGS_HID, 0, SIXDGS_HID, 16, w->m4k, 16, 0, o4k, 0},                                       // Wk W4: writes keys, rows not permuted
   };
   for (const L& l : layers)
     hipLaunchKernelGGL(k_weight_planes, dim3((unsigned)sdg_cdiv((int64_t)l.n * l.kslabs * 4, 256)), dim3(256), 0, s, l.src, l.n, l.ld, l.c0, l.kcols, l.kslabs,
@@ -744,7 +754,7 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
   int* sa = xs + 2 * mp;
   int* sb = sa + 4 * mp;
   const size_t o1 = 0, o2 = o1 + (size_t)512 * 5 * kSlabB, o3 = o2 + (size_t)512 * 16 * kSlabB, o4 = o3 + (size_t)512 * 21 * kSlabB,
-               ok = o4 + (size_t)384 * 16 * kSlabB;
+               ok = o4 + (size_t)384 * 16 * kSlabB, o4k = ok + (size_t)384 * 12 * kSlabB;
   hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs, cm);
   int st;
   DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
@@ -753,6 +763,12 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
   if ((st = launch_dense(l2, s))) return st;
   DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l3, s))) return st;
+  if (dense_fold_kproj()) {
+    // layer 4 and k_proj as ONE layer on h3: fp32 keys, or (kplanes) the scorer's key planes, tile scales and key-norm maximum
+    DenseArgs l4k = {wplanes + o4k, w->m4k, w->b4k, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, kplanes, nullptr, kplanes ? nullptr : kdst, SIXDGS_D, 0,
+                     kplanes ? reinterpret_cast<unsigned*>(knorm_max) : nullptr, cm, 0, kplanes ? kinv : nullptr};
+    return launch_dense(l4k, s);
+  }
   // layer 4 has 384 outputs: 3 blocks; its planes reuse hp2 with 12 slabs per ray
   DenseArgs l4 = {wplanes + o4, w->m4, w->b4, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, hp2, sb, nullptr, 0, 0, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l4, s))) return st;

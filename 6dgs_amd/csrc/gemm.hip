@@ -286,6 +286,28 @@ __global__ void __launch_bounds__(SIXDGS_D) k_q_proj(const float* __restrict__ t
   for (int t = 0; t < kQTok; ++t) qo[(int64_t)t * SIXDGS_D + n] = (t0 + t < nt) ? acc[t] + bv : 0.f;
 }
 
+// Layer 4 of the ray MLP has no non-linearity behind it (ray_preprocessor.py:27-31,46) and k_proj follows at once
+// (our_multihead_attention.py:74): K = Wk (W4 h3 + b4) + bk = (Wk W4) h3 + (Wk b4 + bk).  The composite is formed ONCE per set of weights,
+// in fp64 (products of two fp32 values are exact in fp64; 384 of them accumulate to ~1e-16 relative), and rounded to fp32 once.
+//   w4k[i][j] = sum_m wk[i][m] w4[m][j]     b4k[i] = sum_m wk[i][m] b4[m] + bk[i]
+__global__ void __launch_bounds__(256) k_compose_w4k(const float* __restrict__ wk, const float* __restrict__ bk, const float* __restrict__ w4,
+                                                     const float* __restrict__ b4, float* __restrict__ w4k, float* __restrict__ b4k) {
+  __shared__ float wrow[SIXDGS_D];
+  const int i = blockIdx.x;                        // output row
+  for (int m = threadIdx.x; m < SIXDGS_D; m += 256) wrow[m] = wk[(int64_t)i * SIXDGS_D + m];
+  __syncthreads();
+  for (int j = threadIdx.x; j < SIXDGS_HID + 1; j += 256) {      // column SIXDGS_HID: the bias
+    double acc = 0.0;
+    if (j < SIXDGS_HID) {
+      for (int m = 0; m < SIXDGS_D; ++m) acc = fma((double)wrow[m], (double)w4[(int64_t)m * SIXDGS_HID + j], acc);
+      w4k[(int64_t)i * SIXDGS_HID + j] = (float)acc;
+    } else {
+      for (int m = 0; m < SIXDGS_D; ++m) acc = fma((double)wrow[m], (double)b4[m], acc);
+      b4k[i] = (float)(acc + (double)bk[i]);
+    }
+  }
+}
+
 constexpr size_t pad64(size_t x) { return (x + 63) / 64 * 64; }
 constexpr size_t kOffW1 = 0;
 constexpr size_t kOffB1 = kOffW1 + pad64(512 * 144);
@@ -304,8 +326,11 @@ constexpr size_t kOffM2 = kOffM1 + pad64(512);
 constexpr size_t kOffM3 = kOffM2 + pad64(512);
 constexpr size_t kOffM4 = kOffM3 + pad64(512);
 constexpr size_t kOffMk = kOffM4 + pad64(384);
-constexpr size_t kOffPlanes = kOffMk + pad64(384);  // scaled fp16 planes of W1 .. Wk for the plane-to-plane chain (dense.hip)
-constexpr size_t kPlaneFloats = (512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12) * 32;
+constexpr size_t kOffW4k = kOffMk + pad64(384);     // Wk W4 [384][512], Wk b4 + bk [384] and its row maxima: k_proj folded into layer 4 (round 5)
+constexpr size_t kOffB4k = kOffW4k + pad64(384 * 512);
+constexpr size_t kOffM4k = kOffB4k + pad64(384);
+constexpr size_t kOffPlanes = kOffM4k + pad64(384);  // scaled fp16 planes of W1 .. Wk, Wk W4 for the plane-to-plane chain (dense.hip)
+constexpr size_t kPlaneFloats = (512 * 5 + 512 * 16 + 512 * 21 + 384 * 16 + 384 * 12 + 384 * 16) * 32;
 constexpr size_t kPackedFloats = kOffPlanes + pad64(kPlaneFloats);
 
 // per ray of a chunk: fp32-operand chain x, h1, h2 + three row-maximum arrays = 1171 floats; plane-to-plane chain fp32 keys (384 floats)
@@ -361,6 +386,9 @@ int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* m
   rowmax(kOffW3, 512, 656, kOffM3);
   rowmax(kOffW4, 384, 512, kOffM4);
   rowmax(kOffWk, 384, 384, kOffMk);
+  hipLaunchKernelGGL(k_compose_w4k, dim3(SIXDGS_D), dim3(256), 0, s, packed + kOffWk, packed + kOffBk, packed + kOffW4, packed + kOffB4, packed + kOffW4k,
+                     packed + kOffB4k);
+  rowmax(kOffW4k, 384, 512, kOffM4k);
   SDG_LAUNCH_OK();
   out->w1 = packed + kOffW1; out->b1 = packed + kOffB1;
   out->w2 = packed + kOffW2; out->b2 = packed + kOffB2;
@@ -369,6 +397,7 @@ int sixdgs_pack_weights(const float* mlp0_w, const float* mlp0_b, const float* m
   out->wk = packed + kOffWk; out->bk = packed + kOffBk;
   out->wq = packed + kOffWq; out->bq = packed + kOffBq;
   out->m1 = packed + kOffM1; out->m2 = packed + kOffM2; out->m3 = packed + kOffM3; out->m4 = packed + kOffM4; out->mk = packed + kOffMk;
+  out->w4k = packed + kOffW4k; out->b4k = packed + kOffB4k; out->m4k = packed + kOffM4k;
   out->planes = packed + kOffPlanes;
   return dense_pack_weight_planes(out, reinterpret_cast<char*>(packed + kOffPlanes), s);
 }

@@ -28,7 +28,7 @@ _SCENE_FIELDS = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_res
 
 
 _single_rank_group = False     # a process group of ONE rank is in use (SIXDGS_DIST_SINGLE=1): every collective still runs through the backend
-_long_group = None             # the group with the long timeout (stages one rank may spend hours in: training), created on first use
+_long_group = None             # the group with the long timeout (stages one rank may spend hours in: training); created AND warmed by init_from_env
 _long_group_timeout_s = None
 
 
@@ -60,6 +60,12 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tup
         if os.environ.get("SIXDGS_DIST_TIMEOUT_S"):
             kw["timeout"] = datetime.timedelta(seconds=int(os.environ["SIXDGS_DIST_TIMEOUT_S"]))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        # The long-wait group exists -- communicator included -- BEFORE any long stage: with nccl = RCCL a new group's
+        # communicator is built lazily on its FIRST collective, where the peers wait for rank 0's unique id in the store under the
+        # DEFAULT group's timeout (10 min).  Created inside agree() that first collective came after rank 0's hours of training: the
+        # peers timed out in the store long before.  One tiny all-reduce here, while every rank is at the same point, builds it.
+        _single_rank_group = single
+        warm_long_wait_group(None if backend == "gloo" else torch.device("cuda", torch.cuda.current_device()))
     if single and dist.is_initialized():
         _single_rank_group = True
     return rank, world, local
@@ -70,14 +76,28 @@ def is_dist() -> bool:
 
 
 def long_wait_group():
-    """The process group for collectives a rank may wait hours in (SIXDGS_DIST_LONG_TIMEOUT_S, default 12 h).  Created collectively on
-    first use -- every rank reaches its first long-wait stage at the same point of the sweep."""
+    """The process group for collectives a rank may wait hours in (SIXDGS_DIST_LONG_TIMEOUT_S, default 12 h).  init_from_env creates
+    it and runs its first collective (warm_long_wait_group); a process group initialised elsewhere gets it on first use -- collectively,
+    so call warm_long_wait_group() right after init_process_group in that case."""
     global _long_group, _long_group_timeout_s
     t = int(os.environ.get("SIXDGS_DIST_LONG_TIMEOUT_S", str(12 * 3600)))
     if _long_group is None or _long_group_timeout_s != t:
         _long_group = dist.new_group(timeout=datetime.timedelta(seconds=t))
         _long_group_timeout_s = t
     return _long_group
+
+
+def warm_long_wait_group(device=None) -> None:
+    """Create the long-wait group and run one 4-byte all-reduce on it, so that its communicator exists on every rank from now on.
+    Collective: every rank calls it at the same point (init_from_env does)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    g = long_wait_group()
+    dev = "cpu" if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    one = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=g)
+    if int(one.item()) != dist.get_world_size():
+        raise RuntimeError(f"6dgs_amd: long-wait group saw {int(one.item())} of {dist.get_world_size()} ranks")
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -129,26 +149,40 @@ def broadcast_module(module: torch.nn.Module, src: int = 0):
     return module
 
 
-def gather_poses(c2w: torch.Tensor, status: Optional[torch.Tensor] = None, dst: int = 0):
-    """Per-rank c2w [b_i,4,4] (b_i may differ) -> on `dst`: concatenation in rank order; None elsewhere."""
+def gather_poses(c2w: torch.Tensor, status: Optional[torch.Tensor] = None, dst: int = 0, counts: Optional[list] = None):
+    """Per-rank c2w [b_i,4,4] (b_i may differ, 0 included) -> on `dst`: concatenation in rank order; None elsewhere.
+
+    counts: the b_i of ALL ranks when the caller knows them -- it does whenever the images were cut with shard_range, or every rank
+    scores the same batch size (bench.py) -- then the call is ONE fixed-size gather to `dst` (north_star: "a final gather") with no
+    host synchronisation on the other ranks.  Without counts the sizes are exchanged first (one all_gather of an integer + a host
+    read per rank: round 4 paid that on every step)."""
     if not is_dist():
         return c2w, status
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([c2w.shape[0]], dtype=torch.int64, device=c2w.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        counts = all_counts(int(c2w.shape[0]), c2w.device)
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[rank] != int(c2w.shape[0]):
+            raise RuntimeError(f"6dgs_amd: gather_poses: counts {counts} do not describe rank {rank}'s block of {int(c2w.shape[0])} poses")
     mx = max(counts) if counts else 0
+    if mx == 0:
+        return (c2w, status) if rank == dst else (None, None)
     payload = torch.zeros(mx, 17, dtype=torch.float32, device=c2w.device)
     payload[: c2w.shape[0], :16] = c2w.reshape(-1, 16)
     if status is not None:
         payload[: c2w.shape[0], 16] = status.float()
-    bufs = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(bufs, payload)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, bufs, dst=dst)
     if rank != dst:
         return None, None
     allp = torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
-    return allp[:, :16].reshape(-1, 4, 4), allp[:, 16].to(torch.int32)
+    return allp[:, :16].reshape(-1, 4, 4), (allp[:, 16].to(torch.int32) if status is not None else None)
+
+
+def shard_counts(n: int, world: int) -> list:
+    """Block sizes of shard_range(n, r, world) for r = 0 .. world-1 (the `counts` of gather_poses)."""
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
 def rank() -> int:
@@ -382,7 +416,10 @@ def gather_selected_rays(gidx: torch.Tensor, ori_local: torch.Tensor, dir_local:
     loc = gidx - int(ray_offset)
     mine = (gidx >= 0) & (loc >= 0) & (loc < r_local)
     safe = torch.where(mine, loc, torch.zeros_like(loc))
-    both = torch.cat([ori_local[safe], dir_local[safe]], dim=-1) * mine[..., None].to(ori_local.dtype)
+    if r_local == 0:       # a rank whose ray slice is empty owns no selected ray (found by the 8-rank rehearsal: indexing an empty slice raised)
+        both = torch.zeros(*gidx.shape, 6, dtype=ori_local.dtype, device=ori_local.device)
+    else:
+        both = torch.cat([ori_local[safe], dir_local[safe]], dim=-1) * mine[..., None].to(ori_local.dtype)
     if is_dist() and group is not False:
         _all_reduce(both, dist.ReduceOp.SUM, group)
     return both[..., :3].contiguous(), both[..., 3:].contiguous()

@@ -293,9 +293,9 @@ def main():
             c2w_local = tp.resolve_poses(idm, sol, sol["packed"].cpu())
             if not dd.is_dist():
                 return c2w_local, sol
-            c2w, st = dd.gather_poses(c2w_local.to(dev), sol["status"], 0)
+            c2w, st = dd.gather_poses(c2w_local.to(dev), sol["status"], 0, counts=[args.batch] * world)
             return (c2w if c2w is not None else c2w_local).cpu(), sol
-        c2w, st = dd.gather_poses(sol["c2w"], sol["status"], 0)
+        c2w, st = dd.gather_poses(sol["c2w"], sol["status"], 0, counts=[args.batch] * world)      # one fixed-size gather to rank 0
         host = (c2w if c2w is not None else sol["c2w"]).cpu()   # all poses on the host = end of the step
         return host, sol
 
@@ -488,7 +488,7 @@ def reference_mode_figure(args, pkg, syn, tp, dd, idm, scene, dev, rank, world, 
 
     def one():
         sol = tp.estimate_poses(idm, images, ori, dr, rgb)
-        c2w, _ = dd.gather_poses(sol["c2w"], sol["status"], 0)
+        c2w, _ = dd.gather_poses(sol["c2w"], sol["status"], 0, counts=[batch] * world)
         return (c2w if c2w is not None else sol["c2w"]).cpu()
 
     one()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 4   /* 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 5   /* 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -175,7 +175,12 @@ typedef struct sixdgs_scorer_weights {
   const float* m3; /* [512] */
   const float* m4; /* [384] */
   const float* mk; /* [384] */
-  const void* planes; /* w1 .. wk pre-split into scaled fp16 planes [row][k-slabs][2][32] (w3 as [h | x padded to 160]): the operands of the
+  /* k_proj folded into layer 4 (no non-linearity between them: ray_preprocessor.py:27-31,46, our_multihead_attention.py:74):
+   * K = (Wk W4) h3 + (Wk b4 + bk), composed in fp64 by sixdgs_pack_weights and rounded to fp32 once */
+  const float* w4k; /* [384][512] */
+  const float* b4k; /* [384] */
+  const float* m4k; /* [384] max |w4k| per row */
+  const void* planes; /* w1 .. wk, w4k pre-split into scaled fp16 planes [row][k-slabs][2][32] (w3 as [h | x padded to 160]): the operands of the
                          plane-to-plane ray MLP chain that sixdgs_ray_keys_ex runs when only keys / key planes are asked for */
 } sixdgs_scorer_weights;
 
