@@ -69,11 +69,12 @@ SIGNATURES = {
     "sixdgs_key_planes_norm_max": (i32, [vp, vp, i64, vp, vp]),
     "sixdgs_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_select_candidates_workspace_bytes": (sz, [i64, i32, i32, i32]),
-    "sixdgs_select_begin": (i32, [vp, vp, i32, vp, vp, i64, i64, vp, vp, vp, sz, vp]),
+    "sixdgs_select_begin": (i32, [vp, vp, vp, i32, vp, vp, i64, i64, vp, vp, vp, sz, vp]),
+    "sixdgs_select_sweep_plan": (i32, [vp, i32, vp, vp, i32]),
     "sixdgs_select_sweep": (i32, [vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, i64, vp, vp, sz, vp, C.POINTER(Profile)]),
     "sixdgs_select_candidates": (i32, [vp, i64, i64, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
     "sixdgs_select_rescore": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
-    "sixdgs_select_sample_stats": (i32, [vp, vp, i32, vp, vp, i64, vp, vp, sz, vp]),
+    "sixdgs_select_sample_stats": (i32, [vp, vp, vp, i32, vp, vp, i64, vp, vp, sz, vp]),
     "sixdgs_select_prepare": (i32, [vp, vp, i32, i64, i64, vp, vp, vp]),
     "sixdgs_select_topk_u": (i32, [vp, i64, i64, vp, i32, i32, vp, vp, sz, vp]),
     "sixdgs_linear_splitk_workspace_bytes": (sz, [i64, i32, i32]),

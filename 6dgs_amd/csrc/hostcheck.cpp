@@ -138,6 +138,28 @@ unsigned hc_dl_cm_src_offset(unsigned ray_in_tile, unsigned chunk8, unsigned gra
   return dl::cm_src_offset(ray_in_tile, chunk8 * (unsigned)dl::kChunkRun, granule_stride);
 }
 int hc_sweep_launch_images(int left, int cap) { return sdg::sweep_launch_images(left, cap); }
+// sweep_pack flattened: per launch hc_sweep_pack_ints() ints = n_slots, n_images, q_img[slots][4], q_lq[slots][4], img[], img_nq[], img_q[][4]
+int hc_sweep_pack_ints() { return 2 + 2 * sdg::kSweepMaxSlots * sdg::kSlotQuarters + (2 + sdg::kSlotQuarters) * sdg::kSweepMaxLaunchImages; }
+int hc_sweep_max_slots() { return sdg::kSweepMaxSlots; }
+int hc_sweep_pack(const int* h_n_tok, int batch, int cap, int* out, int max_launches) {
+  const std::vector<sdg::SweepSlots> plan = sdg::sweep_pack(h_n_tok, batch, cap);
+  const int per = hc_sweep_pack_ints();
+  for (size_t l = 0; l < plan.size() && (int)l < max_launches; ++l) {
+    const sdg::SweepSlots& t = plan[l];
+    int* o = out + (size_t)l * per;
+    *o++ = t.n_slots;
+    *o++ = t.n_images;
+    for (int s = 0; s < sdg::kSweepMaxSlots; ++s)
+      for (int w = 0; w < sdg::kSlotQuarters; ++w) *o++ = t.q_img[s][w];
+    for (int s = 0; s < sdg::kSweepMaxSlots; ++s)
+      for (int w = 0; w < sdg::kSlotQuarters; ++w) *o++ = t.q_lq[s][w];
+    for (int i = 0; i < sdg::kSweepMaxLaunchImages; ++i) *o++ = t.img[i];
+    for (int i = 0; i < sdg::kSweepMaxLaunchImages; ++i) *o++ = t.img_nq[i];
+    for (int i = 0; i < sdg::kSweepMaxLaunchImages; ++i)
+      for (int w = 0; w < sdg::kSlotQuarters; ++w) *o++ = t.img_q[i][w];
+  }
+  return (int)plan.size();
+}
 int hc_dl_const(int which) {
   const int v[] = {dl::kSlabB, dl::kPRow, dl::kGran, dl::kGranSlab, dl::kChunkRun};
   return which >= 0 && which < 5 ? v[which] : -1;

@@ -476,6 +476,8 @@ struct LogitsF16Args {
   unsigned* sib_sync;    // [n_sets] zeroed before the launch
   int sib_period;        // tiles between two meetings of a sibling set (>= 1)
   unsigned sib_extra;    // arrivals a set waits for beyond its members: 0.  (1 = SIXDGS_SIBLING_SYNC=3, the test of the bounded wait: a sibling never shows up)
+  int q_quarter_scales;  // 0: qinv [B][2], one scale per 128-token half (k_split_tiles_f16); 1: qinv [B][4], one per 64-token quarter (k_split_q_slots:
+                         // the select sweep's packed slots, where the quarters of a tile belong to different images)
 };
 // what the kernel leaves behind for each tile
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const float cq = A.qinv[2 * b + (wm >> 1)];
+  const float cq = A.q_quarter_scales ? A.qinv[4 * b + wm] : A.qinv[2 * b + (wm >> 1)];
   const bool active = wm * 64 < M;
   float ct[2] = {0.f, 0.f};
   if (OUT == kOutUB) {
@@ -1452,23 +1454,146 @@ __global__ void __launch_bounds__(kT) k_sel_prepare(const float* __restrict__ st
   ctok[(int64_t)bl * kT + t] = ok ? -(m * kLog2e) - (log2f(z) + log2_frac) : -INFINITY;
 }
 
-// U[bl][r] = sum of the token-quarter partials that exist (waves whose 64 tokens are all padding write nothing); tmax (or null): the
-// largest U of every 256-ray tile = of the 4 x 64 rays one wave of this kernel handles.  The k-th largest tile maximum is a lower bound
-// of the k-th largest U (k tiles hold a ray that large) and, with the top rays scattered over 10^5 tiles, almost equal to it: the
-// candidate stage takes its threshold from the tile maxima (r / 256 values) instead of a radix select over all r values of U.
-__global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub, int64_t stride, int64_t u_stride, const int* __restrict__ n_tok, int b0,
-                                                    int64_t R, float* __restrict__ U, float* __restrict__ tmax, int64_t tmax_stride) {
-  const int bl = blockIdx.y;
-  const int nq = (n_tok[b0 + bl] + 63) >> 6;
+// ---- token packing (round 5; sweep_plan.h): the small kernels around the sweep that know which image sits in which quarter of which slot ----------
+// The sweep kernel itself does not: it sees `n_slots` "images" of up to 256 token rows, their planes, per-row ctok and row counts.
+//
+// q rows of the launch's slots -> scaled fp16 planes [slot][256 rows][1536 B] with one power-of-two scale per QUARTER (the scale rule of
+// k_split_tiles_f16 on 64 rows: an image's planes do not depend on the quarter it lands in, nor on its neighbours), inv_scale [slot][4];
+// rows at or beyond the image's token count and unassigned quarters are zero.  Also the slot's ctok row (or null: the sample pre-pass has none) and
+// its number of token rows (what the sweep kernel takes as the "image's" token count).  One workgroup per (slot, quarter).
+__global__ void __launch_bounds__(256) k_split_q_slots(const float* __restrict__ q, const int* __restrict__ n_tok, const SweepSlots T, char* __restrict__ dst,
+                                                       float* __restrict__ inv_scale, const float* __restrict__ ctok, float* __restrict__ ctok_slot,
+                                                       int* __restrict__ slot_rows) {
+  __shared__ float wmax[4];
+  const int slot = blockIdx.x >> 2, w = blockIdx.x & 3;
+  const int img = T.q_img[slot][w], lq = T.q_lq[slot][w];
+  const int n = img < 0 ? 0 : min(64, max(0, n_tok[img] - 64 * lq));
+  const float* base = q + ((int64_t)(img < 0 ? 0 : img) * kT + 64 * (lq < 0 ? 0 : lq)) * SIXDGS_D;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n * 96; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * 4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = sdg_wave_max(m);
+  if (sdg_lane() == 0) wmax[sdg_wave()] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int sh = 0;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    frexpf(m, &e);
+    sh = 14 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  }
+  const float sc = ldexpf(1.f, sh);
+  if (threadIdx.x == 0) inv_scale[blockIdx.x] = ldexpf(1.f, -sh);
+  char* const drow = dst + ((int64_t)slot * kT + 64 * w) * kRowF;
+  for (int i = threadIdx.x; i < 64 * 48; i += 256) {
+    const int row = i / 48, k8 = i - row * 48;
+    f16x8 h, l;
+    if (row < n) {
+      const float* sp = base + (int64_t)row * SIXDGS_D + k8 * 8;
+      const float4 lo = *reinterpret_cast<const float4*>(sp);
+      const float4 hi = *reinterpret_cast<const float4*>(sp + 4);
+      const float x[8] = {lo.x * sc, lo.y * sc, lo.z * sc, lo.w * sc, hi.x * sc, hi.y * sc, hi.z * sc, hi.w * sc};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)x[e];
+        h[e] = hh;
+        l[e] = (_Float16)(x[e] - (float)hh);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = l[e] = (_Float16)0.f;
+    }
+    char* d = drow + (int64_t)row * kRowF + (k8 >> 2) * kSlabF + (k8 & 3) * 16;
+    *reinterpret_cast<f16x8*>(d) = h;
+    *reinterpret_cast<f16x8*>(d + 64) = l;
+  }
+  if (ctok_slot != nullptr && threadIdx.x < 64) {
+    const int t = threadIdx.x;
+    ctok_slot[(int64_t)slot * kT + 64 * w + t] = t < n ? ctok[(int64_t)img * kT + 64 * lq + t] : -INFINITY;
+  }
+  if (w == 0 && threadIdx.x == 0) {      // token rows of the slot: up to the last row of the last quarter that holds any
+    int rows = 0;
+    for (int x = 0; x < kSlotQuarters; ++x) {
+      const int im = T.q_img[slot][x];
+      const int nx = im < 0 ? 0 : min(64, max(0, n_tok[im] - 64 * T.q_lq[slot][x]));
+      if (nx > 0) rows = 64 * x + nx;
+    }
+    slot_rows[slot] = rows;
+  }
+}
+
+// k_merge_stats per IMAGE of a packed launch: image T.img[blockIdx.x], its token quarter blockIdx.y (local tokens 64 y ..) sits in (slot, tile quarter)
+// T.img_q[..][y] of the launch's partials.  The same merge order as k_merge_stats (16 lanes per token over the groups, then ascending).  gsum != null:
+// gsum[img][t] += the merged sum (the sweep: partials are (0, sum) pairs); otherwise stats[img][t] = (max, sumexp) (the sample pre-pass).  Quarters the
+// image does not have: (-inf, 0) / nothing added.
+__global__ void __launch_bounds__(1024) k_merge_stats_slots(const float* __restrict__ partial, int n_groups, const SweepSlots T, float* __restrict__ stats,
+                                                            float* __restrict__ gsum) {
+  __shared__ float sm[16][64][2];
+  const int k = blockIdx.x, y = blockIdx.y, tl = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int img = T.img[k], sq = y < T.img_nq[k] ? T.img_q[k][y] : -1;
+  float m = -INFINITY, s = 0.f;
+  if (sq >= 0) {
+    const float* p = partial + (int64_t)(sq >> 2) * n_groups * kT * 2;
+    const int row = 64 * (sq & 3) + tl;
+    for (int g = j; g < n_groups; g += 16) {
+      const float mt = p[((int64_t)g * kT + row) * 2], st = p[((int64_t)g * kT + row) * 2 + 1];
+      if (mt > -INFINITY) {
+        const float mn = fmaxf(m, mt);
+        s = s * expf(m - mn) + st * expf(mt - mn);
+        m = mn;
+      }
+    }
+  }
+  sm[j][tl][0] = m;
+  sm[j][tl][1] = s;
+  __syncthreads();
+  if (j == 0) {
+    m = -INFINITY;
+    s = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 16; ++qd) {
+      const float mt = sm[qd][tl][0], st = sm[qd][tl][1];
+      if (mt > -INFINITY) {
+        const float mn = fmaxf(m, mt);
+        s = s * expf(m - mn) + st * expf(mt - mn);
+        m = mn;
+      }
+    }
+    const int64_t o = (int64_t)img * kT + 64 * y + tl;
+    if (gsum != nullptr) {
+      gsum[o] += s;
+    } else {
+      stats[o * 2] = m;
+      stats[o * 2 + 1] = s;
+    }
+  }
+}
+
+// k_sel_finish per IMAGE of a packed launch: U[img][r] = sum over the image's quarters, in quarter order, of their rows of partial sums (row 4 slot +
+// tile quarter of ub, wherever the quarter was laid).  The quarters read are those the table gave the image AND its device token count fills (the others
+// were never written).  The table is planned from the caller's HOST copy of the token counts: should that copy promise fewer quarters than the image
+// has tokens for, the tokens beyond them get no sum (k_merge_stats_slots adds nothing: their gsum stays 0) and k_sel_bounds reports the image
+// undecidable (g_t = 0 for a token that exists) -- it is then scored by the two-pass path instead of silently without some of its tokens.
+// tmax (or null): the largest U of every 256-ray tile = of the 4 x 64 rays one wave of this kernel handles.  The k-th largest tile maximum is a lower
+// bound of the k-th largest U (k tiles hold a ray that large) and, with the top rays scattered over 10^5 tiles, almost equal to it: the candidate stage
+// takes its threshold from the tile maxima (r / 256 values) instead of a radix select over all r values of U.
+__global__ void __launch_bounds__(256) k_sel_finish_slots(const float* __restrict__ ub, int64_t stride, int64_t u_stride, const int* __restrict__ n_tok, const SweepSlots T,
+                                                          int64_t R, float* __restrict__ U, float* __restrict__ tmax, int64_t tmax_stride) {
+  const int k = blockIdx.y, img = T.img[k];
+  const int nq_dev = (min(max(n_tok[img], 0), kT) + 63) >> 6;
+  const int nq = min(nq_dev, (int)T.img_nq[k]);
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   float m = -INFINITY;
   if (i < R) {
     float4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < nq; ++w) {
-      const float4 v = *reinterpret_cast<const float4*>(ub + ((int64_t)bl * 4 + w) * stride + i);
+    for (int y = 0; y < nq; ++y) {
+      const float4 v = *reinterpret_cast<const float4*>(ub + (int64_t)T.img_q[k][y] * stride + i);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    *reinterpret_cast<float4*>(U + (int64_t)bl * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
+    *reinterpret_cast<float4*>(U + (int64_t)img * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
     m = a.x;
     if (i + 1 < R) m = fmaxf(m, a.y);
     if (i + 2 < R) m = fmaxf(m, a.z);
@@ -1477,14 +1602,8 @@ __global__ void __launch_bounds__(256) k_sel_finish(const float* __restrict__ ub
   if (tmax != nullptr) {
     m = sdg_wave_max(m);
     const int64_t tile = (i - 4 * sdg_lane()) >> 8;      // the wave's first ray / 256
-    if (sdg_lane() == 0 && tile * 256 < R) tmax[(int64_t)bl * tmax_stride + tile] = m;
+    if (sdg_lane() == 0 && tile * 256 < R) tmax[(int64_t)img * tmax_stride + tile] = m;
   }
-}
-
-// gsum[bl][t] += the sweep's per-token sum (stats_g holds (0, sum) pairs from k_merge_stats)
-__global__ void __launch_bounds__(kT) k_sel_accumulate(const float* __restrict__ stats_g, float* __restrict__ gsum) {
-  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
-  gsum[i] += stats_g[i * 2 + 1];
 }
 
 // max over the rows of |x_row| for the values the scaled fp16 planes hold, x = (h + l) * inv_scale[row / 128]: one wave per row (48 lanes
@@ -2230,7 +2349,7 @@ struct SelectPlan {
   int64_t stride;      // floats per image row of the ub partials (whole 256-ray tiles)
   int nbc;             // candidate-compaction blocks per image
   int64_t span;
-  size_t o_partial, o_stats, o_qpl, o_ub, o_idxu, o_valu, o_lidx, o_lval, o_info, o_counts, o_offs, o_total, o_cscore, per_image, topk_bytes;
+  size_t o_partial, o_stats, o_qpl, o_ub, o_idxu, o_valu, o_lidx, o_lval, o_info, o_counts, o_offs, o_total, o_cscore, o_slot, per_image, topk_bytes;
 };
 SelectPlan select_plan(int64_t r, int batch, int topk, int cmax, bool with_ub = true) {
   SelectPlan p;
@@ -2253,6 +2372,7 @@ SelectPlan select_plan(int64_t r, int batch, int topk, int cmax, bool with_ub = 
   p.o_offs = take((size_t)p.nbc * sizeof(unsigned));
   p.o_total = take(16);
   p.o_cscore = take((size_t)cmax * sizeof(float));
+  p.o_slot = take((size_t)kT * sizeof(float) + 256);      // packed sweep: the slot's ctok row [256] + its row count
   p.per_image = o;
   const size_t t2 = topk_plan(cmax, batch, topk).bytes;
   p.topk_bytes = tp.bytes > t2 ? tp.bytes : t2;
@@ -2261,7 +2381,8 @@ SelectPlan select_plan(int64_t r, int batch, int topk, int cmax, bool with_ub = 
 struct SelectWs {
   SelectPlan p;
   char *topk_ws, *qplanes;
-  float *partial, *stats, *qinv, *ub, *valU, *lval, *info, *cscore;
+  float *partial, *stats, *qinv, *ub, *valU, *lval, *info, *cscore, *ctok_slot;
+  int* slot_rows;
   int64_t *idxU, *lidx;
   unsigned *counts, *offs;
   int* total;
@@ -2289,6 +2410,8 @@ bool select_ws(void* ws, size_t ws_bytes, int64_t r, int nb, int topk, int cmax,
   w->offs = (unsigned*)field(w->p.o_offs);
   w->total = (int*)field(w->p.o_total);
   w->cscore = (float*)field(w->p.o_cscore);
+  w->ctok_slot = (float*)field(w->p.o_slot);
+  w->slot_rows = (int*)(field(w->p.o_slot) + (size_t)nb * kT * sizeof(float));
   return true;
 }
 
@@ -2348,19 +2471,42 @@ size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, 
   return p.topk_bytes + (size_t)batch * p.per_image;
 }
 
-int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
-                               int64_t r_sample, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
-  SDG_CHECK_ARG(batch >= 0 && r_sample >= 1);
+// slots per launch of the packed sweep (SIXDGS_SWEEP_MAX_IMAGES; before round 5 it counted images -- a slot then held one image)
+static int sweep_slot_cap() {
+  static const int cap = [] { const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES"); return e ? atoi(e) : kSweepMaxImages; }();
+  return cap;
+}
+
+int sixdgs_select_sweep_plan(const int32_t* h_n_tok, int batch, int32_t* slots_per_launch, int32_t* images_per_launch, int max_launches) {
+  if (batch < 0 || batch > 32767 || max_launches < 0 || (max_launches > 0 && (!slots_per_launch || !images_per_launch))) return SIXDGS_E_BADARG;
+  const std::vector<SweepSlots> plan = sweep_pack(h_n_tok, batch, sweep_slot_cap());
+  for (size_t l = 0; l < plan.size() && (int)l < max_launches; ++l) {
+    slots_per_launch[l] = plan[l].n_slots;
+    images_per_launch[l] = plan[l].n_images;
+  }
+  return (int)plan.size();
+}
+
+int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* sample_planes,
+                               const float* d_sample_scale, int64_t r_sample, float* row_stats, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && batch <= 32767 && r_sample >= 1);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && sample_planes && d_sample_scale && row_stats && ws && ((uintptr_t)sample_planes % 16) == 0 &&
                 ((uintptr_t)q % 16) == 0 && ((uintptr_t)ws % 256) == 0);
   hipStream_t s = sdg_stream(stream);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r_sample, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
-  select_q_planes(q, batch, w, s);
-  const LogitsF16Args V = select_args(d_n_tok, batch, w, sample_planes, d_sample_scale, r_sample);
-  hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * batch)), dim3(512), 0, s, V);
-  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch, 4), dim3(1024), 0, s, w.partial, V.n_groups, row_stats);
+  const int n_groups = f16x_groups(r_sample);
+  for (const SweepSlots& T : sweep_pack(h_n_tok, batch, sweep_slot_cap())) {      // token packing: sweep_plan.h
+    if (T.n_slots > 0) {
+      hipLaunchKernelGGL(k_split_q_slots, dim3((unsigned)(4 * T.n_slots)), dim3(256), 0, s, q, d_n_tok, T, w.qplanes, w.qinv, (const float*)nullptr,
+                         (float*)nullptr, w.slot_rows);
+      LogitsF16Args V = select_args(w.slot_rows, T.n_slots, w, sample_planes, d_sample_scale, r_sample);
+      V.q_quarter_scales = 1;
+      hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+    }
+    hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, s, w.partial, n_groups, T, row_stats, (float*)nullptr);
+  }
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -2378,14 +2524,14 @@ int sixdgs_select_prepare(const float* row_stats, const int32_t* d_n_tok, int ba
   return 0;
 }
 
-int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
                         int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && r_sample >= 1 && r_total >= r_sample);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(ws && ((uintptr_t)ws % 256) == 0);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r_sample, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
-  const int st = sixdgs_select_sample_stats(q, d_n_tok, batch, sample_planes, d_sample_scale, r_sample, w.stats, ws, ws_bytes, stream);
+  const int st = sixdgs_select_sample_stats(q, d_n_tok, h_n_tok, batch, sample_planes, d_sample_scale, r_sample, w.stats, ws, ws_bytes, stream);
   if (st) return st;
   return sixdgs_select_prepare(w.stats, d_n_tok, batch, r_sample, r_total, ctok, gsum, stream);
 }
@@ -2393,72 +2539,64 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const
 int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
                         const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
                         void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
-  SDG_CHECK_ARG(batch >= 0 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0 && (!u_tile_max || (u_stride % 256) == 0));
+  SDG_CHECK_ARG(batch >= 0 && batch <= 32767 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0 && (!u_tile_max || (u_stride % 256) == 0));
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && ctok && gsum && u && ws && ((uintptr_t)key_planes % 16) == 0 &&
                 ((uintptr_t)q % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)ws % 256) == 0);
-  // Images per launch are capped (round 4): every sibling streams its OWN q planes (393 KB per image) once per tile, and the images of a launch share an
-  // XCD's 4 MB L2 with the key tiles in flight -- with many images the q planes fall out of it.  Measured (tools/time_sweep.py B 8388608,
+  // Slots per launch are capped (round 4, then per image): every sibling streams its OWN q planes (393 KB per slot) once per tile, and the slots of a launch
+  // share an XCD's 4 MB L2 with the key tiles in flight -- with many of them the q planes fall out of it.  Measured (tools/time_sweep.py B 8388608,
   // profiles/r04_sweep_images_per_launch.log; TFLOP/s fp32-equivalent): one launch for the whole batch 415 / 422 / 413 / 401 / 354 / 278 at 4 / 8 / 12 / 16 / 24 /
-  // 32 images; launches of 8: 423 / 424 / 426 at 16 / 24 / 32.  So a batch goes in launches of kSweepMaxImages, the last one taking what is left up to
-  // kSweepMaxTail (a launch of one or two images would pull every key tile from HBM for itself: 0.455).  Every launch streams the key planes once, i.e.
-  // 1/8 of a sweep's bytes per image; results do not depend on the grouping (batch invariance: tests/test_gpu_full_size.py, test_gpu_select.py).
-  {
-    static const int cap = [] { const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES"); const int v = e ? atoi(e) : kSweepMaxImages; return v; }();
-    if (sweep_launch_images(batch, cap) < batch) {
-      for (int b0 = 0; b0 < batch;) {
-        const int nb = sweep_launch_images(batch - b0, cap);
-        const int st = sixdgs_select_sweep(q + (int64_t)b0 * kT * SIXDGS_D, d_n_tok + b0, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r,
-                                           ctok + (int64_t)b0 * kT, gsum + (int64_t)b0 * kT, u + (int64_t)b0 * u_stride, u_stride,
-                                           u_tile_max ? u_tile_max + (int64_t)b0 * (u_stride / 256) : nullptr, ws, ws_bytes, stream, prof);
-        if (st) return st;
-        b0 += nb;
-      }
-      return 0;
-    }
-  }
+  // 32 images; launches of 8: 423 / 424 / 426 at 16 / 24 / 32.  So a batch goes in launches of kSweepMaxImages slots, the last one taking what is left up to
+  // 1.5 x that (a launch of one or two slots would pull every key tile from HBM for itself: 0.455).  Every launch streams the key planes once.
+  // Round 5: the images of a launch are PACKED into the slots by their token counts (sweep_plan.h) -- two views of <= 128 tokens or four of <= 64 share a
+  // 256-row tile -- so the matrix work AND the key stream per image follow the tokens the mask kept, as the reference's cost does
+  // (backbone.py:86-114, identification_module.py:80-82).  Results do not depend on grouping or packing (tests/test_gpu_select.py, test_gpu_full_size.py).
   hipStream_t s = sdg_stream(stream);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
-  select_q_planes(q, batch, w, s);
-  LogitsF16Args V = select_args(d_n_tok, batch, w, key_planes, d_key_scale, r);
-  V.ctok = ctok;
-  V.ub = w.ub;
-  V.ub_stride = w.p.stride;
-  double tok = 0.0;
-  for (int i = 0; i < batch; ++i) tok += h_n_tok ? (double)h_n_tok[i] : (double)kT;
-  {
-    // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
-    unsigned grid = (unsigned)(V.n_groups * batch);
-    const int cus = sibling_sync_cus();
-    // (persistent sets leave cus % batch CUs idle: only when that is at most 1/16 of the chip -- e.g. not for 100 images per launch)
-    if (cus > 0 && batch >= 2 && cus / batch >= 1 && (cus % batch) * 16 <= cus && w.p.topk_bytes >= (size_t)(cus / batch) * sizeof(unsigned)) {
-      // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
-      V.n_sets = cus / batch < V.n_groups ? cus / batch : V.n_groups;
-      V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
-      V.sib_extra = sibling_sync_mode() == 3 ? 1u : 0u;
-      V.sib_period = kSibPeriod;
-      if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
-      grid = (unsigned)(V.n_sets * batch);
-    }
-    SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + batch * 16.0));
-    auto kern = V.n_sets > 0 ? k_logits_f16x<0, kOutUB, true> : k_logits_f16x<0, kOutUB, false>;
-#ifdef SIXDGS_ABLATION   // timing / power experiments only (tools/power_trace.py abl<N> on a private -DSIXDGS_ABLATION build): the sweep with parts compiled out
-    if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
-#define SDG_ABL_CASE(n) case n: kern = V.n_sets > 0 ? k_logits_f16x<n, kOutUB, true> : k_logits_f16x<n, kOutUB, false>; break;
-      switch (atoi(ab)) {
-        SDG_ABL_CASE(2) SDG_ABL_CASE(18) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59) SDG_ABL_CASE(4096)
-        default: break;
+  const int n_groups = f16x_groups(r);
+  for (const SweepSlots& T : sweep_pack(h_n_tok, batch, sweep_slot_cap())) {
+    const int ns = T.n_slots;
+    double tok = 0.0;
+    for (int k = 0; k < T.n_images; ++k) tok += h_n_tok ? (double)(h_n_tok[T.img[k]] < 0 ? 0 : (h_n_tok[T.img[k]] > kT ? kT : h_n_tok[T.img[k]])) : (double)kT;
+    if (ns > 0) {
+      hipLaunchKernelGGL(k_split_q_slots, dim3((unsigned)(4 * ns)), dim3(256), 0, s, q, d_n_tok, T, w.qplanes, w.qinv, ctok, w.ctok_slot, w.slot_rows);
+      LogitsF16Args V = select_args(w.slot_rows, ns, w, key_planes, d_key_scale, r);
+      V.q_quarter_scales = 1;
+      V.ctok = w.ctok_slot;
+      V.ub = w.ub;
+      V.ub_stride = w.p.stride;
+      // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
+      unsigned grid = (unsigned)(V.n_groups * ns);
+      const int cus = sibling_sync_cus();
+      // (persistent sets leave cus % ns CUs idle: only when that is at most 1/16 of the chip -- e.g. not for 100 slots per launch)
+      if (cus > 0 && ns >= 2 && cus / ns >= 1 && (cus % ns) * 16 <= cus && w.p.topk_bytes >= (size_t)(cus / ns) * sizeof(unsigned)) {
+        // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
+        V.n_sets = cus / ns < V.n_groups ? cus / ns : V.n_groups;
+        V.sib_sync = sibling_sync_mode() == 2 ? nullptr : reinterpret_cast<unsigned*>(w.topk_ws);      // the top-k scratch is idle during the sweep
+        V.sib_extra = sibling_sync_mode() == 3 ? 1u : 0u;
+        V.sib_period = kSibPeriod;
+        if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
+        grid = (unsigned)(V.n_sets * ns);
       }
+      SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + T.n_images * 16.0));
+      auto kern = V.n_sets > 0 ? k_logits_f16x<0, kOutUB, true> : k_logits_f16x<0, kOutUB, false>;
+#ifdef SIXDGS_ABLATION   // timing / power experiments only (tools/power_trace.py abl<N> on a private -DSIXDGS_ABLATION build): the sweep with parts compiled out
+      if (const char* ab = getenv("SIXDGS_DEBUG_ABLATE")) {
+#define SDG_ABL_CASE(n) case n: kern = V.n_sets > 0 ? k_logits_f16x<n, kOutUB, true> : k_logits_f16x<n, kOutUB, false>; break;
+        switch (atoi(ab)) {
+          SDG_ABL_CASE(2) SDG_ABL_CASE(18) SDG_ABL_CASE(11) SDG_ABL_CASE(27) SDG_ABL_CASE(59) SDG_ABL_CASE(4096)
+          default: break;
+        }
 #undef SDG_ABL_CASE
-    }
+      }
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, V);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, V);
+    }
+    hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, s, w.partial, n_groups, T, (float*)nullptr, gsum);
+    hipLaunchKernelGGL(k_sel_finish_slots, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)T.n_images), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, T, r, u,
+                       u_tile_max, u_stride / 256);
   }
-  hipLaunchKernelGGL(k_merge_stats, dim3((unsigned)batch, 4), dim3(1024), 0, s, w.partial, V.n_groups, w.stats);
-  hipLaunchKernelGGL(k_sel_accumulate, dim3((unsigned)batch), dim3(kT), 0, s, w.stats, gsum);
-  hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)batch), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, 0, r, u,
-                     u_tile_max, u_stride / 256);
   SDG_LAUNCH_OK();
   return 0;
 }
@@ -2594,7 +2732,7 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
     const int nb = (int)((batch - b0) < bg ? (batch - b0) : bg);
     const float* qg = q + (int64_t)b0 * kT * SIXDGS_D;
     const int32_t* ng = d_n_tok + b0;
-    int st = sixdgs_select_begin(qg, ng, nb, sample_planes, d_sample_scale, r_sample, r, ctok, gsum, ws, stage, stream);
+    int st = sixdgs_select_begin(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, sample_planes, d_sample_scale, r_sample, r, ctok, gsum, ws, stage, stream);
     if (st) return st;
     st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, utm, ws, stage,
                              stream, prof);

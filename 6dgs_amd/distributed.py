@@ -172,6 +172,7 @@ def gather_poses(c2w: torch.Tensor, status: Optional[torch.Tensor] = None, dst: 
     payload[: c2w.shape[0], :16] = c2w.reshape(-1, 16)
     if status is not None:
         payload[: c2w.shape[0], 16] = status.float()
+    payload = _collective_device(payload)          # gloo moves host memory (a few hundred bytes per image); nccl = RCCL gathers device tensors
     bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
     dist.gather(payload, bufs, dst=dst)
     if rank != dst:

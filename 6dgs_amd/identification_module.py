@@ -28,17 +28,6 @@ def _lib_ray_keys_ws(r: int, max_chunk: int = ops.RAY_KEYS_CHUNK) -> int:
     return int(_lib.load().sixdgs_ray_keys_workspace_bytes(int(r), int(max_chunk)))
 
 
-def launch_classes(n_tok_host):
-    """Images of a batch grouped for the token-aware sweep: -> (rows_of [B]: 64-token wave rows image i needs, order: the images in descending row count
-    (stable: ties keep the caller's order), cuts: boundaries in `order` between two row-count classes, starting with 0 and ending with B).  The images of
-    one launch walk the key tiles in lock-step at the pace of the image with the most rows, so each class gets its own launch."""
-    rows_of = [(int(v) + 63) // 64 for v in n_tok_host]
-    b = len(rows_of)
-    order = sorted(range(b), key=lambda i: -rows_of[i])
-    cuts = [0] + [j for j in range(1, b) if rows_of[order[j]] != rows_of[order[j - 1]]] + [b]
-    return rows_of, order, cuts
-
-
 class RayPreprocessor(torch.nn.Module):
     """Parameter holder with the reference layout (ray_preprocessor.py:11-34)."""
 
@@ -270,24 +259,13 @@ class IdentificationModule(torch.nn.Module):
                     raise RuntimeError("6dgs_amd: the select workspace must exist before a hipGraph capture (run the batch once eagerly)")
                 self._select_ws = sw = None
                 self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
-            # Token-aware launches (round 4): the sweep's waves work in rows of 64 tokens and skip the rows beyond an image's token count, but the
-            # images of ONE launch walk the key tiles in lock-step (sibling sets, they share every tile through L2) -- at the pace of the image
-            # with the most rows.  Masked views differ (Tanks&Temples: 80-176 of 256 tokens), so a batch goes as one launch per ROW-COUNT CLASS:
-            # the images are taken in descending class order and the results put back (a few hundred bytes per image).
-            rows_of, order, cuts = launch_classes(n_host)
-            if len(cuts) == 2 or capturing:      # (inside a hipGraph capture the permutation's H2D copy is not allowed: one launch, lock-step pace)
-                idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
-                                                    max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
-                                                    key_norm=kc["norm"])
-            else:
-                perm = torch.tensor(order, dtype=torch.int64, device=q.device)
-                q_s, n_s = q.index_select(0, perm), n_tok.index_select(0, perm)
-                parts = [ops.score_select(q_s[c0:c1], n_s[c0:c1], kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
-                                          max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile,
-                                          n_tok_host=[n_host[i] for i in order[c0:c1]], key_norm=kc["norm"]) for c0, c1 in zip(cuts[:-1], cuts[1:])]
-                cat = [torch.cat([p[j] for p in parts]) for j in range(3)]                   # sorted position i holds image order[i]
-                idx, val, status = (torch.empty_like(c).index_copy_(0, perm, c) for c in cat)
-            self.last_select_launch_classes = [rows_of[order[c]] for c in cuts[:-1]]
+            # Token packing (round 5): the library packs the images of a launch into the sweep's 256-token tiles by their token counts (two views of
+            # <= 128 tokens or four of <= 64 share a tile; csrc/sweep_plan.h) -- masked views (Tanks&Temples / Blender keep 56-176 of 256 tokens) cost what
+            # their tokens cost, in ONE call with nothing permuted on the host.  (Round 4 ran one full select pipeline per 64-token row-count class here.)
+            idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
+                                                max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
+                                                key_norm=kc["norm"])
+            self.last_select_launches = ops.select_sweep_plan(n_host)          # [(tiles, images)] per sweep launch
             self.last_scoring_path = "select"
             pend = dict(status=status, q=q, n_tok=n_tok, k=rays_to_output, workspace=workspace, images_in_flight=images_in_flight,
                         rays=(rays_ori, rays_dir, rays_rgb))

@@ -553,6 +553,20 @@ def score_select_workspace_bytes(r: int, batch: int, topk: int = 100, max_candid
     return int(_lib.load().sixdgs_score_select_workspace_bytes(int(r), int(batch), int(topk), int(max_candidates)))
 
 
+def select_sweep_plan(n_tok_host, batch: Optional[int] = None):
+    """How the select sweep cuts a batch with these token counts (None: unknown, one image per 256-token tile) into launches:
+    -> list of (tiles, images) per launch (include/sixdgs.h: sixdgs_select_sweep_plan; host arithmetic, no GPU needed)."""
+    lib = _lib.load()
+    b = len(n_tok_host) if n_tok_host is not None else int(batch)
+    h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
+    cap = max(1, b)
+    slots, imgs = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    n = lib.sixdgs_select_sweep_plan(h_n, b, slots, imgs, cap)
+    if n < 0:
+        check(n, "select_sweep_plan")
+    return [(int(slots[i]), int(imgs[i])) for i in range(min(n, cap))]
+
+
 @_on_device
 def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
                  sample_scale: torch.Tensor, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
@@ -560,7 +574,8 @@ def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor,
                  key_norm: Optional[torch.Tensor] = None):
     """Top-k without materialised logits (include/sixdgs.h: sixdgs_score_select).  Returns (idx [B,k], val [B,k], status [B] int32 on
     the device: candidates examined, or -1 = this image needs the two-pass scorer).  key_norm: key_norm_max(key_planes, key_scale),
-    computed here (one more pass over the planes) when not handed in -- callers with a key cache keep it beside the planes."""
+    computed here (one more pass over the planes) when not handed in -- callers with a key cache keep it beside the planes.
+    n_tok_host: list of the token counts (must equal n_tok): masked views then share the sweep's 256-token tiles (token packing)."""
     q = _f32(q)
     _need_gpu(q, n_tok, key_planes, key_scale, sample_planes, sample_scale, key_norm)
     if key_norm is None:
@@ -574,7 +589,8 @@ def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor,
     status = torch.empty(b, dtype=torch.int32, device=dev)
     if workspace is None:
         workspace = torch.empty(score_select_workspace_bytes(r, b, topk, max_candidates), dtype=torch.uint8, device=dev)
-    h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if (profile is not None and n_tok_host is not None) else None
+    # the host copy of the token counts: with it the sweep PACKS the images of a launch by their token counts (round 5; include/sixdgs.h)
+    h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
     check(lib.sixdgs_score_select(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), _p(key_norm), r, _p(sample_planes), _p(sample_scale), rs,
                                   int(topk), int(max_candidates), _p(idx), _p(val), _p(status), _p(workspace), workspace.numel(), _stream(),
                                   profile.ref if profile is not None else None), "score_select")
@@ -613,7 +629,7 @@ class SelectStream:
         _need_gpu(self.q, sample_planes, sample_scale)
         lib = _lib.load()
         self._grow(lib.sixdgs_select_workspace_bytes(sample_planes.shape[0], self.b, self.topk, self.cmax))
-        check(lib.sixdgs_select_begin(_p(self.q), _p(self.n_tok), self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0], self.r,
+        check(lib.sixdgs_select_begin(_p(self.q), _p(self.n_tok), self.h_n, self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0], self.r,
                                       _p(self.ctok), _p(self.gsum), _p(self.ws), self.ws.numel(), _stream()), "select_begin")
 
     @_on_device
@@ -623,7 +639,7 @@ class SelectStream:
         lib = _lib.load()
         self._grow(lib.sixdgs_select_workspace_bytes(sample_planes.shape[0], self.b, self.topk, self.cmax))
         stats = torch.empty(self.b, MAX_TOKENS, 2, device=self.dev)
-        check(lib.sixdgs_select_sample_stats(_p(self.q), _p(self.n_tok), self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0],
+        check(lib.sixdgs_select_sample_stats(_p(self.q), _p(self.n_tok), self.h_n, self.b, _p(sample_planes), _p(sample_scale), sample_planes.shape[0],
                                              _p(stats), _p(self.ws), self.ws.numel(), _stream()), "select_sample_stats")
         return stats
 
@@ -659,7 +675,7 @@ class SelectStream:
         lib = _lib.load()
         rc = planes.shape[0]
         self._grow(lib.sixdgs_select_workspace_bytes(rc, self.b, self.topk, self.cmax))
-        check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n if profile is not None else None, self.b, _p(planes), _p(scale), rc,
+        check(lib.sixdgs_select_sweep(_p(self.q), _p(self.n_tok), self.h_n, self.b, _p(planes), _p(scale), rc,
                                       _p(self.ctok), _p(self.gsum), C.c_void_p(self.u.data_ptr() + 4 * int(ray_offset)), self.stride,
                                       C.c_void_p(self.utm.data_ptr() + 4 * (int(ray_offset) // 256)),
                                       _p(self.ws), self.ws.numel(), _stream(), profile.ref if profile is not None else None), "select_sweep")

@@ -187,6 +187,73 @@ def resolve_poses(id_module, sol, packed_host):
     return again["c2w"].cpu()
 
 
+class PoseStream:
+    """Batches of query images through `estimate_poses` as a PIPELINE: the reference's evaluation is exactly such a stream of views
+    (pose_estimation/test.py:46-302), and poses/s over a test set is what the metric counts.
+
+      handle = ps.submit(images, gt)      # enqueue everything of this batch; returns at once
+      c2w, sol = ps.collect(handle)       # later: the batch's poses on the host
+
+    With one batch submitted before the previous one is collected, (a) the host never sits between the GPU's last kernel of batch N and its
+    first of batch N + 1 (round 4: every step ended in a device sync before the next image side was even enqueued), and (b) the image side of
+    batch N + 1 -- ~250 small kernels, ViT-S/14 + camera-up CNN -- runs on its OWN stream, so it fills the compute units the sweep of batch N
+    frees in its tail and overlaps batch N's small serial kernels (finish of U, selections, re-score, pose solve, D2H).  The scorer itself
+    stays in order on the caller's stream (one sweep holds every CU: its registers and LDS leave room for nothing else).
+    Poses are bit-identical to the unpipelined run: the same kernels on the same data in the same order per batch.
+
+    Inputs of batch N must exist before submit(N - 1) was called, or be produced on `ps.image_stream` (uploads under
+    `with torch.cuda.stream(ps.image_stream)`): the image stream does not wait for the caller's stream beyond that point."""
+
+    def __init__(self, id_module, rays_ori, rays_dirs, rays_rgb, k: int = 100, workspace=None, images_in_flight=None):
+        self.idm, self.rays, self.k = id_module, (rays_ori, rays_dirs, rays_rgb), k
+        self.workspace, self.images_in_flight = workspace, images_in_flight
+        self.image_stream = torch.cuda.Stream(device=rays_ori.device)
+        self._fence = None            # recorded on the caller's stream at the START of the previous submit
+
+    @torch.no_grad()
+    def submit(self, images, gt_c2w=None, profile=None, tokens=None, up=None):
+        main = torch.cuda.current_stream()
+        side = self.image_stream
+        if tokens is None:
+            if self._fence is None:
+                side.wait_stream(main)
+            else:
+                side.wait_event(self._fence)
+            fence = torch.cuda.Event()
+            fence.record(main)
+            self._fence = fence
+            with torch.cuda.stream(side):
+                cache = self.idm.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
+                res = cache.run(self.idm, images)
+                if res is not None and not isinstance(res[0], (list, tuple)):
+                    # the graph's outputs are STATIC buffers, rewritten by the next replay: this batch keeps its own copy (1.6 MB at 4 images)
+                    tk, u = res
+                    tokens = type(tk)(tk.feats.clone(), tk.pe) if hasattr(tk, "feats") else tk.clone()
+                    up = u.clone()
+                else:
+                    imgs_f, masks = prepare_images_device(images)
+                    tokens, fmaps = self.idm.image_tokens(imgs_f, masks)
+                    up = self.idm.camera_up(fmaps)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            main.wait_event(ready)
+            for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))) + [up]:
+                t.record_stream(main)          # allocated on the image stream, read on the caller's
+        sol = estimate_poses(self.idm, None, *self.rays, gt_c2w=gt_c2w, k=self.k, workspace=self.workspace, images_in_flight=self.images_in_flight,
+                             profile=profile, tokens=tokens, up=up, defer_status=True)
+        host = torch.empty(sol["packed"].shape, dtype=sol["packed"].dtype, pin_memory=True)
+        host.copy_(sol["packed"], non_blocking=True)        # the batch's ONE D2H, behind an event instead of a device sync
+        done = torch.cuda.Event()
+        done.record(main)
+        return {"sol": sol, "host": host, "done": done}
+
+    @torch.no_grad()
+    def collect(self, handle):
+        """-> (c2w [B,4,4] on the host, sol).  Images the select path refused are re-done here by the two-pass scorer (rare)."""
+        handle["done"].synchronize()
+        return resolve_poses(self.idm, handle["sol"], handle["host"]), handle["sol"]
+
+
 @torch.no_grad()
 def estimate_poses_ray_sharded(id_module, images, rays_ori, rays_dirs, rays_rgb, ray_offset: int, r_total: int, gt_c2w=None, k: int = 100,
                                profile=None, tokens=None, up=None, image_graph: bool = True, group=None):

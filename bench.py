@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole per-batch path (image prep, ViT, CNN, scorer, pose solve) in one hipGraph and replay it "
                          "per step: for the launch-bound small-scene regime (--mode reference); kernel timing needs the eager path")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one batch at a time, every step ending in a device sync (rounds 1-4).  Default: two batches in flight (6dgs_amd.test.PoseStream): "
+                         "batch N + 1 is submitted -- its image side on a second stream -- before batch N's poses are collected; same poses bit for bit")
     ap.add_argument("--no-select", action="store_true",
                     help="score with the two-pass scorer (logits through HBM) instead of the select path (top-k without materialised logits)")
     ap.add_argument("--l32-steps", type=int, default=-1,
@@ -105,6 +108,9 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
     ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
     ap.add_argument("--streamed-batch", type=int, default=32, help="cfg5-standin: images per step of a streamed scene (one pass of the ray MLP serves them all)")
+    ap.add_argument("--stream-above-rays", type=int, default=0,
+                    help="cfg5-standin: score scenes with more rays than this streamed even when their key planes would fit (0 = by HBM size only); lets a "
+                         "reduced-scale run exercise the streamed class")
     ap.add_argument("--oracle-rays", type=int, default=1 << 20, help="cfg5-standin: rays of the per-scene oracle check (a prefix of the scene)")
     args = ap.parse_args()
     for k, v in PRESETS[args.config].items():
@@ -169,21 +175,36 @@ def main():
     ranks_seen = dd.ranks_seen(dev)          # an all-reduce of ones over the process group (RCCL when world > 1)
 
     # ---- scene: rank 0 owns it, RCCL broadcast of the Gaussian arrays, local re-emission ------------------
+    # Set-up is itemised (VERDICT r4 #3a): every item ends in a device sync and the items add up to scene_setup_s.total.  "standin_*" items exist only
+    # because the scene is synthesised here; the reference reads a PLY (pretrain_eval_attention.py:89).
     t_setup = time.time()
+    setup_items, t_lap = {}, [time.time()]
+
+    def lap(name):
+        torch.cuda.synchronize()
+        now = time.time()
+        setup_items[name] = round(setup_items.get(name, 0.0) + now - t_lap[0], 3)
+        t_lap[0] = now
+
     scene = None
+    host_scene = syn.make_scene(args.gaussians, 0) if rank == 0 else None
+    lap("standin_host_scene_generation")
     if rank == 0:
-        scene = pkg.GaussianScene.from_dict(syn.make_scene(args.gaussians, 0), device=dev)
+        scene = pkg.GaussianScene.from_dict(host_scene, device=dev)
         if args.scene == "ply":                # the on-disk format either side of the path: 3DGS point_cloud.ply (gaussian_model.py:284-420)
             with tempfile.TemporaryDirectory() as td:
                 path = os.path.join(td, "point_cloud", "iteration_30000", "point_cloud.ply")
                 scene.save_ply(path)
+                lap("standin_ply_write")
                 scene = pkg.GaussianScene.load_ply(path, sh_degree=3, device=dev)
+    del host_scene
     scene = dd.broadcast_scene(scene, 0, device=dev)
+    lap("scene_read_upload_and_broadcast")
     idm = pkg.IdentificationModule("dino")
     idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0, with_cnn=True).items()}, strict=False)
     idm = idm.to(dev).eval()
     dd.broadcast_module(idm, 0)
-    torch.cuda.synchronize()
+    lap("module_weights_init_upload_and_broadcast")
     t0 = time.time()
     if args.parallelism == "auto":
         planes_per_rank = args.gaussians * args.rays_per_ellipsoid * 1536 / max(world, 1)
@@ -208,6 +229,7 @@ def main():
         ori, dr, rgb = pkg.generate_all_possible_rays(scene)
     torch.cuda.synchronize()
     t_emit = time.time() - t0
+    lap("normals_knn_and_emission")
     R = int(ori.shape[0])
     ray_offset, R_total = 0, R
     if ray_sharded and dd.is_dist():            # this rank's rays are [ray_offset, ray_offset + R) of R_total
@@ -232,10 +254,12 @@ def main():
         torch.cuda.synchronize()
         t_alloc = time.time() - ta
         del tmp
+        lap("key_plane_buffer_alloc")
         t0 = time.time()
         idm._ensure_keys(ori, dr, rgb, profile=kprof, sample_min_rays=max(4096, ops.SELECT_MIN_RAYS // world) if ray_sharded else None)
         torch.cuda.synchronize()
         k_ms, k_fl, _, _ = kprof.collect()
+        lap("ray_mlp_key_planes_and_sample")
     t_keys = time.time() - t0
     if not streamed:
         # images whose [256, R] logits are resident at once (they share every key tile through L2): --in-flight, or as many
@@ -262,6 +286,7 @@ def main():
 
     if not streamed and not use_select and not ray_sharded:
         two_pass_ws()
+    lap("scorer_workspace")
     t_setup = time.time() - t_setup
 
     # ---- query images resident on the device ------------------------------------------------------------------
@@ -314,15 +339,43 @@ def main():
             graph_sol = run_batch(None)
         graph = g
 
+    # Pipelined steps (default where the path allows it: select scorer on resident planes, image-sharded, no whole-step graph): the evaluation is a
+    # stream of batches (test.py:46-302), so batch N + 1 is SUBMITTED before batch N's poses are collected -- the host never sits between two batches
+    # and the image side of N + 1 (own stream) overlaps the small serial kernels behind sweep N.  Every batch still ends with its poses on the host.
+    pipelined = bool(use_select and not args.graph and not args.no_pipeline and not ray_sharded and not streamed)
+    ps = tp.PoseStream(idm, ori, dr, rgb, workspace=ws) if pipelined else None
+    last_host = [None]
+
     def timed(n_steps, p):
-        """exactly n_steps steps bracketed by barrier + synchronize; (max-over-ranks seconds, per-step seconds, last results)"""
+        """exactly n_steps steps bracketed by barrier + synchronize; (max-over-ranks seconds, per-step seconds, last results).  Pipelined: per-step
+        seconds are the intervals between the COMPLETIONS of consecutive batches (poses on the host); with several ranks the poses of all steps go
+        to rank 0 in ONE fixed-size gather at the end (north_star: "a final gather") instead of one per step behind the next batch's sweep."""
         torch.cuda.synchronize()
         dd.barrier()
         per, t_begin = [], time.perf_counter()
-        for _ in range(n_steps):
-            t1 = time.perf_counter()
-            host, s = step(p)
-            per.append(time.perf_counter() - t1)
+        if ps is None or not use_select or not ops.select_enabled():
+            for _ in range(n_steps):
+                t1 = time.perf_counter()
+                host, s = step(p)
+                per.append(time.perf_counter() - t1)
+            last_host[0] = host
+        else:
+            prev, t1, local = None, t_begin, []
+            for i in range(n_steps + 1):
+                cur = ps.submit(images, gts, profile=p) if i < n_steps else None
+                if prev is not None:
+                    c2w_local, s = ps.collect(prev)
+                    local.append(c2w_local)
+                    t2 = time.perf_counter()
+                    per.append(t2 - t1)
+                    t1 = t2
+                prev = cur
+            host = local[-1]
+            if dd.is_dist():
+                allp, _ = dd.gather_poses(torch.cat(local).to(dev), None, 0, counts=[args.batch * n_steps] * world)
+                if allp is not None:
+                    host = allp.cpu().view(world, n_steps, args.batch, 4, 4)[:, -1].reshape(-1, 4, 4)
+            last_host[0] = host
         torch.cuda.synchronize()
         dd.barrier()
         return dd.max_over_ranks(time.perf_counter() - t_begin, dev), per, s
@@ -373,7 +426,8 @@ def main():
         "scaling": "strong" if ray_sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "median_step": {"ms": round(1e3 * med, 3), "poses_per_s": round(img_ranks * args.batch / med, 4), "n": len(per_step),
                         "min_ms": round(1e3 * min(per_step), 3), "max_ms": round(1e3 * max(per_step), 3),
-                        "note": "rank-0 wall time of each timed step (every step ends with the poses on the host)"},
+                        "note": ("rank-0 interval between the completions of consecutive batches (poses of the batch on the host); two batches in flight"
+                                 if pipelined else "rank-0 wall time of each timed step (every step ends with the poses on the host)")},
         "arithmetic": ("fp32 results; q.K^T and the ray MLP / k_proj as 2 power-of-two-scaled fp16 planes x 3 MFMA terms (q_proj, CNN: 3 bf16 planes x 6 "
                        "terms), fp32 accumulation (measured error <= that of the fp32 MFMA chain)"
                        + ("; select path: no logits stored, candidates re-scored in fp32 (nothing below fp32 on the path)" if ("select" in path and not path.startswith("streamed")) else
@@ -388,22 +442,27 @@ def main():
                          + "; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
             "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R_total, "images_per_gpu_per_step": args.batch,
             "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
-            # select path: the library sweeps a batch of more than 12 images in launches of 8 (csrc/sweep_plan.h; SIXDGS_SWEEP_MAX_IMAGES)
-            "images_per_select_sweep_launch": (args.batch if args.batch <= 12 else 8),
+            "pipeline": ("2 batches in flight (6dgs_amd.test.PoseStream): batch N + 1 submitted before batch N's poses are collected, its image side on a second "
+                         "stream; scorer in order on one stream; one D2H per batch behind an event; --no-pipeline = one batch at a time" if pipelined
+                         else "none: one batch at a time, a device sync per step"),
+            # select path: how the library cut this batch into sweep launches -- (256-token tiles, images) per launch, from the library's own planner with
+            # the token counts of the last batch (csrc/sweep_plan.h: launches of 8 tiles, images packed into tiles by token count; SIXDGS_SWEEP_MAX_IMAGES)
+            "select_sweep_launches": getattr(idm, "last_select_launches", None),
             "parallelism": (f"ray-sharded x{world} (scene broadcast over RCCL, every rank emits and keeps the key planes of its block of ellipsoids: "
                             f"{R} of {R_total} rays on rank 0; per batch a few KB of all-reduce / all-gather: sample statistics, g_t, U_(k), candidates)"
                             if ray_sharded else f"image-sharded x{world} (scene broadcast over RCCL, local re-emission, pose gather)"),
             "mma": mma_name[mode],
         },
         "ranks_seen": ranks_seen, "backend": dd.backend_name(),
-        "scene_setup_s": {"total": round(t_setup, 3), "normals+emission": round(t_emit, 3), "key_plane_buffer_alloc": round(t_alloc, 3),
+        "scene_setup_s": {"total": round(t_setup, 3), "breakdown": setup_items,
+                          "standin": round(sum(v for k_, v in setup_items.items() if k_.startswith("standin_")), 3), "normals+emission": round(t_emit, 3), "key_plane_buffer_alloc": round(t_alloc, 3),
                           "ray_mlp_keys": round(t_keys, 3), "ray_mlp_keys_kernels": round(k_ms * 1e-3, 3),
                           "ray_mlp_keys_tflops": round(k_fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None,
                           "note": "key_plane_buffer_alloc = first hipMalloc of the 1536 B/ray plane buffer (once per process, reused across scenes); "
                                   "ray_mlp_keys = wall time of the ray MLP + k_proj chain incl. the select path's ray sample; _kernels = its HIP-event time"},
     }
     if os.environ.get("SIXDGS_BENCH_DUMP_POSES"):        # test hook: the poses of the last timed step in the line
-        out["poses_last_step"] = sol["c2w"].cpu().tolist()
+        out["poses_last_step"] = sol["c2w"].cpu().tolist()          # (the device tensor of the last batch: identical with and without the pipeline)
     if streamed:
         out["config"]["chunk_rays"] = args.chunk_rays
         out["config"]["scoring_note"] = ("key planes of the whole scene (1536 B/ray) exceed one GPU: ray chunks go through the ray MLP + k_proj and the scorer "

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 5   /* 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 5   /* 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -309,7 +309,16 @@ int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t
  * from sixdgs_ray_keys_ex on the gathered rays. */
 size_t sixdgs_select_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);              /* begin, sweep: r = rays of the call */
 size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, int max_candidates);   /* candidates (r = all rays), rescore */
-int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+/* h_n_tok (begin, sample_stats, sweep, sixdgs_score_select; may be NULL): a HOST copy of d_n_tok.  With it the images of a launch are PACKED by their
+ * token counts into the 256-token tiles of the matrix-core sweep (two views of <= 128 tokens, four of <= 64, 192 + 64 ... share a tile; ABI 5), so a
+ * masked view costs what its surviving tokens cost (the reference scores only those: backbone.py:86-114, identification_module.py:80-82).  It MUST equal
+ * d_n_tok; an image the host copy gives too few tokens is reported undecidable (status -1), never scored without some of its tokens.  Results do not
+ * depend on it: an image's U, sums and statistics are the same bits packed or alone.  NULL: one image per tile (and 256 tokens each in the FLOP count). */
+/* How sixdgs_select_sweep / _sample_stats / sixdgs_score_select cut `batch` images with these token counts (NULL: unknown) into launches: returns the
+ * number of launches (>= 0; < 0 an error) and fills, for the first max_launches of them, the 256-token tiles ("slots") and the images of each.  Host
+ * arithmetic only (csrc/sweep_plan.h); for reporting and tests. */
+int sixdgs_select_sweep_plan(const int32_t* h_n_tok, int batch, int32_t* slots_per_launch, int32_t* images_per_launch, int max_launches);
+int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
                         int64_t r_sample, int64_t r_total, float* ctok, float* gsum, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 /* Ray-sharded select (the scene's key planes split over ranks, SURVEY 8(e) fallback): `begin` in two halves, so that the shards can
  * merge their sample statistics in between -- sample_stats writes this shard's (max, sumexp) [B,256,2] of ITS sample; the caller
@@ -318,7 +327,7 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, int batch, const
  * sixdgs_select_topk_u (the shard's k largest U, descending, NaN-padded) -> all-gather, k-th largest of the union = U_(k) of the
  * scene -> candidates with d_uk [B] -> rescore with allow_fewer (a shard may hold fewer than k candidates: idx / val are then padded
  * with -1 / NaN and status = candidates examined) -> all-gather + (value desc, global index asc) merge. */
-int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
+int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* sample_planes, const float* d_sample_scale,
                                int64_t r_sample, float* row_stats /*[B,256,2]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 int sixdgs_select_prepare(const float* row_stats, const int32_t* d_n_tok, int batch, int64_t r_sample, int64_t r_total, float* ctok, float* gsum,
                           sixdgs_stream_t stream);

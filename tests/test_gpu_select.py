@@ -41,7 +41,8 @@ def make_case(ops, r, seed, q_scale, n_tok, key_spread=1.0):
 
 
 def check_against_two_pass_and_oracle(ops, oracle, c, k=100, cmax=4096, oracle_images=(0,), allow_giveup=False, tol2=2e-6, tolo=1e-5):
-    idx, val, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], k, max_candidates=cmax)
+    idx, val, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], k, max_candidates=cmax,
+                                        n_tok_host=c["n_tok"])                      # host token counts: the images are packed into the sweep's tiles
     i2, v2, sc, _ = ops.score_topk(c["q"], c["nt"], None, k, key_planes=c["planes"], key_scale=c["scale"], want_scores=True)
     st = status.tolist()
     for b, t in enumerate(c["n_tok"]):
@@ -103,6 +104,59 @@ def test_select_zero_token_image_and_tile_scales(ops, oracle):
     # e^88 somewhere -- the select path must say so (and never answer wrongly)
     c = make_case(ops, 1_100_000, 5, 1.0, (256, 0, 64), key_spread=3.0)
     check_against_two_pass_and_oracle(ops, oracle, c, oracle_images=(), allow_giveup=True, tol2=1e-3)
+
+
+def test_token_packing_is_invisible_and_matches_the_oracle(ops, oracle):
+    """Round 5: views of 40 / 64 / 65 / 128 / 200 tokens (and 256, 137, none) in ONE batch.  With the host token counts the library packs them into
+    256-token tiles (csrc/sweep_plan.h: 17 quarters of 64 tokens laid one after the other into 5 tiles, an image may span two); without them every image sweeps a tile of its own.  Same rays, same values,
+    same candidate counts, bit for bit -- an image's U, per-token sums and sample statistics do not depend on the quarter it sits in nor on its neighbours --
+    and both agree with the two-pass scorer and the CPU oracle."""
+    n_tok = (40, 64, 65, 128, 200, 0, 256, 137)
+    c = make_case(ops, 1_200_037, 31, 6.0, n_tok)
+    plan = ops.select_sweep_plan(list(n_tok))
+    assert plan == [(5, 8)], plan                                    # 5 tiles for 8 images (17 quarters; the image without tokens rides along)
+    assert ops.select_sweep_plan(None, batch=8) == [(8, 8)]
+    packed = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, n_tok_host=list(n_tok))
+    alone = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100)
+    for a, b in zip(packed, alone):
+        assert torch.equal(a, b)
+    # every image by itself (a batch of one: nothing to pack with)
+    for i in (0, 2, 4):
+        one = ops.score_select(c["q"][i:i + 1].contiguous(), c["nt"][i:i + 1].contiguous(), c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100,
+                               n_tok_host=[n_tok[i]])
+        assert torch.equal(one[0][0], packed[0][i]) and torch.equal(one[1][0], packed[1][i]) and int(one[2][0]) == int(packed[2][i])
+    st = check_against_two_pass_and_oracle(ops, oracle, c, oracle_images=(0, 1, 2, 3, 4))
+    assert st[5] == 0 and min(v for i, v in enumerate(st) if i != 5) >= 100
+
+
+def test_token_packing_stage_by_stage_and_a_wrong_host_copy(ops):
+    """The staged entry points (what the streamed and the ray-sharded scorers call) pack as well: U and g_t of a packed sweep over ragged chunks equal the
+    unpacked ones bit for bit.  And a host copy that promises FEWER tokens than the device count is caught: that image comes back undecidable (status
+    -1, scored by the two-pass path), never scored without some of its tokens."""
+    n_tok = (64, 128, 60, 100, 256, 1)
+    c = make_case(ops, 700_123, 41, 6.0, n_tok)
+    runs = []
+    for host in (list(n_tok), None):
+        ss = ops.SelectStream(c["q"], c["nt"], 700_123, 100, 4096, host)
+        ss.begin(c["s_planes"], c["s_scale"])
+        for r0, r1 in ((0, 300_032), (300_032, 700_123)):
+            planes, scale = ops.split_planes_f16(c["key"][r0:r1].contiguous())
+            ss.sweep(planes, scale, r0)
+        cand, count = ss.candidates()
+        runs.append((ss.ctok.clone(), ss.gsum.clone(), ss.u[:, :700_123].clone(), count.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    wrong = list(n_tok)
+    wrong[3] = 64                                                    # image 3 has 100 tokens; the host copy says 64 -> one quarter too few
+    idx, val, status = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, n_tok_host=wrong)
+    good = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, n_tok_host=list(n_tok))
+    assert int(status[3]) == -1 and int(idx[3].max()) == -1
+    for i in (0, 1, 2, 4, 5):
+        assert torch.equal(idx[i], good[0][i]) and torch.equal(val[i], good[1][i])
+    more = list(n_tok)
+    more[0] = 256                                                    # promising MORE tokens than there are only wastes a tile: same answer
+    idx2, val2, st2 = ops.score_select(c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, n_tok_host=more)
+    assert torch.equal(idx2, good[0]) and torch.equal(val2, good[1]) and torch.equal(st2, good[2])
 
 
 def test_select_reports_what_it_cannot_decide(ops):
