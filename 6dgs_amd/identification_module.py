@@ -127,6 +127,9 @@ class IdentificationModule(torch.nn.Module):
                         for h, t in zip(held, (rays_ori, rays_dir, rays_rgb))))       # the held (hence still allocated) memory
         if not same:
             self._key_cache = self._key_cache_rays = None        # drop the old planes before allocating the new ones
+            if ops.get_arena() is not None:                      # ... and with an arena everything else that was carved from it for the old scene
+                self._select_ws = self._stream_sample = None
+                ops.get_arena().reset()
             r = rays_ori.shape[0]
             planes_mode = mode != ops.MMA_F32
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
@@ -206,6 +209,8 @@ class IdentificationModule(torch.nn.Module):
         """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
         self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = self._peq = None
+        if ops.get_arena() is not None:       # the planes / workspaces just dropped were carved from it (an arena serves ONE module: ops.Arena)
+            ops.get_arena().reset()
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
@@ -258,7 +263,7 @@ class IdentificationModule(torch.nn.Module):
                 if capturing:
                     raise RuntimeError("6dgs_amd: the select workspace must exist before a hipGraph capture (run the batch once eagerly)")
                 self._select_ws = sw = None
-                self._select_ws = sw = torch.empty(need, dtype=torch.uint8, device=q.device)
+                self._select_ws = sw = ops.big_empty(need, torch.uint8, q.device)
             # Token packing (round 5): the library packs the images of a launch into the sweep's 256-token tiles by their token counts (two views of
             # <= 128 tokens or four of <= 64 share a tile; csrc/sweep_plan.h) -- masked views (Tanks&Temples / Blender keep 56-176 of 256 tokens) cost what
             # their tokens cost, in ONE call with nothing permuted on the host.  (Round 4 ran one full select pipeline per 64-token row-count class here.)
@@ -371,22 +376,28 @@ class IdentificationModule(torch.nn.Module):
             ident = (r, rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key)
             if not (held is not None and held[0] == ident and all(h.data_ptr() == t.data_ptr() for h, t in zip(held[1], (rays_ori, rays_dir, rays_rgb)))):
                 self._stream_sample = held = None
+                if ops.get_arena() is not None:                  # a new scene: what the arena held for the previous one goes
+                    self._key_cache = self._key_cache_rays = self._select_ws = None
+                    ops.get_arena().reset()
                 si = ops.select_sample_indices(r, dev)
                 _, _, (sp, sscale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
                 self._stream_sample = held = (ident, (rays_ori, rays_dir, rays_rgb), sp, sscale)      # once per scene, like the key cache
-            ss = ops.SelectStream(q, n_tok, r, k, cmax, n_host)
-            ss.begin(held[2], held[3])
-            for r0 in range(0, r, chunk):
-                r1 = min(r0 + chunk, r)
-                _, _, (planes, scale) = ops.ray_keys(rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1], w, want_key=False, want_planes=True,
-                                                     norm_out=ss.key_norm)
-                ss.sweep(planes, scale, r0, profile, update_norm=False)
-                del planes, scale
-            cand, count = ss.candidates()
-            inside = torch.arange(cmax, device=dev)[None, :] < count.clamp(min=0, max=cmax)[:, None]
-            ci = torch.where(inside, cand, torch.zeros_like(cand)).reshape(-1)
-            _, _, (cp, cs) = ops.ray_keys(rays_ori[ci], rays_dir[ci], rays_rgb[ci], w, want_key=False, want_planes=True)
-            idx, val, status = ss.rescore(cp, cs, cand, count, compact=True)
+            with ops.arena_scope():          # U, the stage workspaces and the chunks' planes: given back to the arena (if any) when the batch is enqueued
+                ss = ops.SelectStream(q, n_tok, r, k, cmax, n_host)
+                ss.reserve(max(min(chunk, r), int(held[2].shape[0])))
+                ss.begin(held[2], held[3])
+                for r0 in range(0, r, chunk):
+                    r1 = min(r0 + chunk, r)
+                    with ops.arena_scope():  # one chunk's key planes
+                        _, _, (planes, scale) = ops.ray_keys(rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1], w, want_key=False, want_planes=True,
+                                                             norm_out=ss.key_norm)
+                        ss.sweep(planes, scale, r0, profile, update_norm=False)
+                        del planes, scale
+                cand, count = ss.candidates()
+                inside = torch.arange(cmax, device=dev)[None, :] < count.clamp(min=0, max=cmax)[:, None]
+                ci = torch.where(inside, cand, torch.zeros_like(cand)).reshape(-1)
+                _, _, (cp, cs) = ops.ray_keys(rays_ori[ci], rays_dir[ci], rays_rgb[ci], w, want_key=False, want_planes=True)
+                idx, val, status = ss.rescore(cp, cs, cand, count, compact=True)
             st = status.tolist()                         # the one host sync of the path
             self.last_select_candidates = st
             redo = [i for i, v in enumerate(st) if v < 0]

@@ -391,6 +391,83 @@ RAY_KEYS_CHUNK = 1 << 20
 RAY_KEYS_CHUNK_MIN = 1 << 16
 
 
+class Arena:
+    """ONE device buffer from which the big per-scene buffers are carved: key planes (1536 B per ray), the select workspace (20 B per ray and image), the
+    ray-MLP chain's workspace, a streamed scene's U and chunk planes.  An evaluation sweep walks scenes of very different sizes
+    (pretrain_eval_attention.py:224-247: 19 M to 392 M rays in the stand-in sweep): through PyTorch's caching allocator every larger scene meant a new
+    100-200 GB hipMalloc (pages mapped and cleared at 30-75 GB/s: seconds) and, because a cached block that small tensors have split can neither be reused
+    nor released, an `empty_cache()` between scenes that re-paid it for EVERY scene (round 4: 38 s of set-up against 28 s of evaluation).  The ABI's own
+    rule -- the caller provides the workspace -- points at one allocation made once: a bump allocator, reset per scene, with scopes for what lives
+    shorter (a chunk of a streamed scene).  Everything carved from it is used on ONE stream (reuse is ordered by the stream); the pipeline's image
+    stream never touches it.  Opt-in: `with ops.use_arena(arena): ...` / `ops.set_arena(arena)`; without one the allocations go to torch as before."""
+
+    def __init__(self, nbytes: int, device):
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        self.off, self.high = 0, 0
+
+    @property
+    def capacity(self) -> int:
+        return int(self.buf.numel())
+
+    def take(self, nbytes: int, align: int = 4096) -> torch.Tensor:
+        base = self.buf.data_ptr()
+        off = (base + self.off + align - 1) // align * align - base          # the ADDRESS is aligned (kernels ask for 16 .. 256 B; 4 KB keeps pages apart)
+        if off + int(nbytes) > self.buf.numel():
+            raise RuntimeError(f"6dgs_amd: arena exhausted ({off + int(nbytes)} of {self.buf.numel()} bytes asked for)")
+        self.off = off + int(nbytes)
+        self.high = max(self.high, self.off)
+        return self.buf[off:self.off]
+
+    def mark(self) -> int:
+        return self.off
+
+    def release(self, mark: int) -> None:
+        self.off = int(mark)
+
+    def reset(self) -> None:
+        self.off = 0
+
+
+_arena: Optional[Arena] = None
+ARENA_MIN_BYTES = 1 << 22          # smaller buffers stay with torch's allocator
+
+
+def set_arena(arena: Optional[Arena]) -> Optional[Arena]:
+    """Install (or, with None, remove) the arena the big buffers come from; returns the previous one."""
+    global _arena
+    prev, _arena = _arena, arena
+    return prev
+
+
+def get_arena() -> Optional[Arena]:
+    return _arena
+
+
+class arena_scope:
+    """`with ops.arena_scope():` -- what is taken from the arena inside is given back at the end (no-op without an arena)."""
+
+    def __enter__(self):
+        self.m = _arena.mark() if _arena is not None else None
+        return self
+
+    def __exit__(self, *exc):
+        if _arena is not None and self.m is not None:
+            _arena.release(self.m)
+        return False
+
+
+def big_empty(shape, dtype, device) -> torch.Tensor:
+    """torch.empty for the path's big buffers: from the arena when one is installed on this device (and the buffer is big), else from torch."""
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    nbytes = n * torch.empty(0, dtype=dtype).element_size()
+    a = _arena
+    if a is not None and nbytes >= ARENA_MIN_BYTES and a.buf.device == torch.device(device):
+        return a.take(nbytes).view(dtype).view(shape)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 def _free_bytes(dev) -> int:
     """Device memory a new tensor can still get: what the driver reports free + what PyTorch's caching allocator holds unused."""
     free = torch.cuda.mem_get_info(dev)[0]
@@ -418,21 +495,23 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     key = torch.empty(r, D, device=dev) if want_key else None
     mode = effective_mma_mode()
     f16 = want_planes and mode in F16_MODES
-    planes = torch.empty(r, 1536 if f16 else 2304, dtype=torch.uint8, device=dev) if want_planes else None
+    planes = big_empty((r, 1536 if f16 else 2304), torch.uint8, dev) if want_planes else None
     inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     if workspace is None or workspace.numel() < nbytes:
         # 6560 B of transient workspace per ray of a chunk (6.9 GB at the default 2^20 rays): next to a scene that nearly fills the HBM the
         # chunk shrinks instead of the allocation failing -- any chunking gives the same keys bit for bit, smaller chunks are 3 % slower
         chunk = int(max_chunk)
-        while chunk > RAY_KEYS_CHUNK_MIN and nbytes > 0.5 * _free_bytes(dev):
+        room = (_arena.capacity - _arena.off) if (_arena is not None and _arena.buf.device == dev) else 0.5 * _free_bytes(dev)
+        while chunk > RAY_KEYS_CHUNK_MIN and nbytes > room:
             chunk //= 2
             nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, chunk)
-    ws = workspace if workspace is not None and workspace.numel() >= nbytes else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if norm_out is not None and not f16:
         raise RuntimeError("6dgs_amd: norm_out needs scaled fp16 key planes (want_planes in MMA_F16X3 mode)")
-    check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(norm_out), _p(ws), ws.numel(),
-                                 _stream(), profile.ref if profile is not None else None, mode), "ray_keys")
+    with arena_scope():         # the chain's workspace is transient: back to the arena when the call is enqueued (reuse is ordered by the stream)
+        ws = workspace if workspace is not None and workspace.numel() >= nbytes else big_empty(nbytes, torch.uint8, dev)
+        check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(norm_out), _p(ws), ws.numel(),
+                                     _stream(), profile.ref if profile is not None else None, mode), "ray_keys")
     if want_planes:
         return feat, key, ((planes, inv) if f16 else planes)
     return feat, key
@@ -613,7 +692,7 @@ class SelectStream:
         self.stride = (self.r + 255) // 256 * 256
         self.ctok = torch.empty(self.b, MAX_TOKENS, device=self.dev)
         self.gsum = torch.empty(self.b, MAX_TOKENS, device=self.dev)
-        self.u = torch.empty(self.b, self.stride, device=self.dev)
+        self.u = big_empty((self.b, self.stride), torch.float32, self.dev)
         self.utm = torch.empty(self.b, self.stride // 256, device=self.dev)        # the largest U of every 256-ray tile (candidate threshold)
         self.key_norm = torch.zeros(1, device=self.dev)        # max |k_r| over the chunks swept so far (the bound of the candidate stage)
         self.ws = torch.empty(1, dtype=torch.uint8, device=self.dev)
@@ -622,7 +701,14 @@ class SelectStream:
     def _grow(self, need):
         if self.ws.numel() < need:
             self.ws = None
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws = big_empty(need, torch.uint8, self.dev)       # (from an arena: the smaller predecessor stays taken until the caller's scope ends)
+
+    def reserve(self, chunk_rows: int):
+        """Grow the stage workspace ONCE to what sweep(chunk of `chunk_rows` rays), candidates() and rescore() will ask for -- callers that take the
+        chunks' planes from an arena inside a per-chunk scope must not have the workspace grow (and be given back) inside such a scope."""
+        lib = _lib.load()
+        self._grow(max(lib.sixdgs_select_workspace_bytes(int(chunk_rows), self.b, self.topk, self.cmax),
+                       lib.sixdgs_select_candidates_workspace_bytes(self.r, self.b, self.topk, self.cmax)))
 
     @_on_device
     def begin(self, sample_planes, sample_scale):

@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
     ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
     ap.add_argument("--streamed-batch", type=int, default=32, help="cfg5-standin: images per step of a streamed scene (one pass of the ray MLP serves them all)")
+    ap.add_argument("--no-arena", action="store_true", help="cfg5-standin: big per-scene buffers from PyTorch's caching allocator with empty_cache() between scenes (round 4) instead of one arena")
     ap.add_argument("--stream-above-rays", type=int, default=0,
                     help="cfg5-standin: score scenes with more rays than this streamed even when their key planes would fit (0 = by HBM size only); lets a "
                          "reduced-scale run exercise the streamed class")

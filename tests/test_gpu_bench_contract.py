@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -221,4 +222,6 @@ def test_evaluation_sweep_with_eight_ranks_on_one_gpu(tmp_path):
     assert len(outs[0]) == len(outs[1]) >= 12
     for a, b in zip(*outs):
         assert (a["sequence_id"], a["frame_id"]) == (b["sequence_id"], b["frame_id"])
-        assert a["gt_c2w"] == b["gt_c2w"] and a["pred_c2w"] == b["pred_c2w"]
+        assert a["gt_c2w"] == b["gt_c2w"]
+        # (the backbone's GEMMs see batches of 3 views in one run and of 1 in the other: library kernels are not bit-stable across batch sizes)
+        assert np.abs(np.asarray(a["pred_c2w"]) - np.asarray(b["pred_c2w"])).max() < 1e-5

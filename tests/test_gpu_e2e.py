@@ -134,6 +134,40 @@ def test_a24_test_pose_estimation(pkg, e2e):
     assert len(back) == n and np.array(back[0]["pred_c2w"]).shape == (4, 4) and back[0]["frame_id"] == 0
 
 
+def test_a24_streamed_inference_pass_equals_one_batch_at_a_time(pkg, e2e, syn, monkeypatch):
+    """Round 5: the inference pass of test_pose_estimation runs as a pipeline (PoseStream: batch N + 1 decoded, uploaded and through the image side
+    while batch N is scored; one D2H per batch behind an event).  Same result dicts as the loop that syncs after every batch (SIXDGS_NO_PIPELINE=1):
+    (a) the golden scene with injected tokens, (b) real images through the backbone on a scene large enough for the select path -- RGB views of one
+    size in one batch (the image-side hipGraph) and masked RGBA views (ragged token counts, eager) in the others."""
+    g, idm, cams = e2e
+    n = int(g["e2e_n"])
+    ori, dr, rgb = G(g["n3000_p50_ori"]), G(g["n3000_p50_dir"]), G(g["n3000_p50_rgb"])
+    toks = [G(g[f"e2e{i}_tokens"]) for i in range(n)]
+    ups = torch.stack([G(g[f"e2e{i}_up"]) for i in range(n)])
+    up0 = torch.tensor([0.0, 1.0, 0.0])
+
+    def both(fn):
+        monkeypatch.delenv("SIXDGS_NO_PIPELINE", raising=False)
+        a = fn()
+        monkeypatch.setenv("SIXDGS_NO_PIPELINE", "1")
+        b = fn()
+        monkeypatch.delenv("SIXDGS_NO_PIPELINE")
+        return a, b
+
+    a, b = both(lambda: pkg.test_pose_estimation(cams, idm, ori, dr, rgb, up0, "seq", "cat", token_override=toks, up_override=ups, verbose=False, batch_size=3))
+    assert a[0] == b[0] and a[1:] == b[1:] and len(a[0]) == n
+    # (b) images: 4 RGB + 3 masked RGBA views (structured alpha: a proper subset of the tokens survives), batches of 4 -> [RGB x4] (graph), [RGBA x3]
+    rays = syn.make_rays(1_300_000, 3)
+    o2, d2, c2 = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+    views = [pkg.CameraInfo(**c) for c in syn.make_cameras(4, 900, width=96, height=80)]
+    views += [pkg.CameraInfo(**c) for c in syn.make_masked_cameras(11, size=120)]
+    a, b = both(lambda: pkg.test_pose_estimation(views, idm, o2, d2, c2, up0, "seq", "cat", verbose=False, batch_size=4))
+    assert idm.last_scoring_path.startswith("select")
+    assert len(a[0]) == 7 and [r["frame_id"] for r in a[0]] == list(range(7))
+    assert a[0] == b[0]                                                     # every field of every result dict, bit for bit
+    assert all(x == y or (x != x and y != y) for x, y in zip(a[1:], b[1:]))
+
+
 def test_a24_save_and_save_all_dump(pkg, e2e, tmp_path):
     """test.py:94-106,137-140,164-166,202-214: `save=True` dumps image 0, `save_all=True` every image, as sample_results_<i>.th with the
     reference's keys (into `save_dir` instead of the reference's hard-coded home directory); the dump agrees with the returned results and
