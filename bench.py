@@ -383,6 +383,8 @@ def main():
 
     for _ in range(args.warmup):
         step(None)
+        if ps is not None and use_select and ops.select_enabled():      # ... and through the pipelined path itself (its stream, its first graph replay there, its pinned buffers)
+            ps.collect(ps.submit(images, gts))
     elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
     if args.graph:        # HIP events cannot be read out of a captured graph: the kernel's duration comes from a few EAGER steps of the same batch
         g_keep, graph = graph, None
@@ -487,8 +489,8 @@ def main():
                 tj = json.load(open(args.traffic_json))
                 if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight and tj.get("path", "two-pass") == ("select" if ("select" in path and not path.startswith("streamed")) else "two-pass"):
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = ("%s -- builder's separate rocprofv3 --pmc pass over this same command (round %s), NOT measured in this run"
-                                      % (tj.get("source", os.path.relpath(args.traffic_json, ROOT)), tj.get("round")))
+                    traffic_source = ("NOT measured in this run: copied from the builder's separate rocprofv3 --pmc pass over this same command (round %s): %s"
+                                      % (tj.get("round"), tj.get("source", os.path.relpath(args.traffic_json, ROOT))))
             except Exception:
                 traffic = None
         ach = l_fl / (l_ms * 1e-3) / 1e12 if l_ms > 0 else 0.0

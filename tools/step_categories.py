@@ -3,7 +3,9 @@
 `k_solve_pose`: one per batch), its kernels summed by CATEGORY (ray-MLP chain, sweep, sample pre-pass, select bookkeeping, top-k, image side, copies,
 other), the idle time of the window and the kernels that follow the longest gaps.  Written for the streamed scorer, whose step is thousands of launches
 (VERDICT r4 #3c: "a quarter of the step is neither chain nor sweep").
-Usage: step_categories.py results.db [out.md] [anchor-substring] [step-from-the-end]"""
+Usage: step_categories.py results.db [out.md] [anchor-substring] [step-from-the-end] [start-anchor-substring]
+(start-anchor: the window opens behind the LAST launch of that kernel before the end anchor instead of behind the previous end anchor -- for a run
+with a single step, e.g. `k_emit_isocell` = the end of a streamed scene's set-up)"""
 import re
 import sqlite3
 import sys
@@ -40,10 +42,20 @@ def main():
     back = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     rows = list(cur.execute(f'select name, "{cs}", "{ce}" from kernels order by "{cs}"'))
     marks = [i for i, r in enumerate(rows) if anchor in r[0]]
-    if len(marks) < back + 1:
-        raise SystemExit(f"only {len(marks)} {anchor} launches in the trace")
-    lo, hi = marks[-back - 1] + 1, marks[-back] + 1
-    t0 = rows[marks[-back - 1]][2]
+    start_anchor = sys.argv[5] if len(sys.argv) > 5 else None
+    if start_anchor:
+        if len(marks) < back:
+            raise SystemExit(f"only {len(marks)} {anchor} launches in the trace")
+        hi = marks[-back] + 1
+        starts = [i for i, r in enumerate(rows[:hi]) if start_anchor in r[0]]
+        if not starts:
+            raise SystemExit(f"no {start_anchor} launch before the end anchor")
+        lo, t0 = starts[-1] + 1, rows[starts[-1]][2]
+    else:
+        if len(marks) < back + 1:
+            raise SystemExit(f"only {len(marks)} {anchor} launches in the trace")
+        lo, hi = marks[-back - 1] + 1, marks[-back] + 1
+        t0 = rows[marks[-back - 1]][2]
     step = rows[lo:hi]
     total = step[-1][2] - t0
     cat_t, cat_n = {}, {}
