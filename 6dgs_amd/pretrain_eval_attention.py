@@ -54,6 +54,10 @@ def parse_args(argv=None):
     ap.add_argument("--n_iterations", type=int, default=1500, help="training iterations when no id_module.th exists")
     ap.add_argument("--skip_train", action="store_true", help="never train: evaluate the checkpoint, or random-init weights when there is none")
     ap.add_argument("--batch_size", type=int, default=16, help="query images per scorer launch")
+    ap.add_argument("--arena_gb", type=float, default=0.0,
+                    help="carve the big per-scene buffers (key planes, select workspace, chain workspace) from ONE device buffer of this many GB allocated once "
+                         "(ops.Arena) instead of asking the allocator scene by scene: a sweep over scenes of growing size otherwise pays a 100-200 GB hipMalloc "
+                         "per scene.  -1: everything free but 56 GB; 0 (default): off")
     return ap.parse_known_args(argv)
 
 
@@ -171,6 +175,15 @@ def main(argv=None, backbone: Optional[torch.nn.Module] = None) -> List[dict]:
         if rank == 0:
             print(f"[6dgs_amd] evaluation sweep over {seen} rank(s), backend {dd.backend_name()}")
     results: List[dict] = []
+    arena = None
+    if args.arena_gb:
+        from . import ops
+        free_b = torch.cuda.mem_get_info(torch.device(device))[0]
+        want = int(free_b - (56 << 30)) if args.arena_gb < 0 else int(args.arena_gb * (1 << 30))
+        arena = ops.Arena(max(1 << 28, min(want, int(0.95 * free_b))), torch.device(device))
+        ops.set_arena(arena)
+        if rank == 0:
+            print(f"[6dgs_amd] arena of {arena.capacity / 2**30:.1f} GiB for the per-scene buffers")
     for exp in parse_exp_dir(args.exp_path, PREFIXES.get(args.data_type, "")).values():
         ckpt_args = get_checkpoint_arguments(exp["exp_dir_filepath"])
         try:
@@ -183,6 +196,9 @@ def main(argv=None, backbone: Optional[torch.nn.Module] = None) -> List[dict]:
                 results.extend(obj)
         except RuntimeError:            # the only exception the reference survives per scene (pretrain_eval_attention.py:243-244)
             traceback.print_exc()
+    if arena is not None:
+        from . import ops
+        ops.set_arena(None)
     if rank == 0:
         print("Saving results")
         with open(out_path_abs, "w") as fh:
