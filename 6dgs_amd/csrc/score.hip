@@ -1589,10 +1589,13 @@ __global__ void __launch_bounds__(256) k_sel_finish_slots(const float* __restric
   float m = -INFINITY;
   if (i < R) {
     float4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int y = 0; y < nq; ++y) {
-      const float4 v = *reinterpret_cast<const float4*>(ub + (int64_t)T.img_q[k][y] * stride + i);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
+    const int64_t row[kSlotQuarters] = {T.img_q[k][0], T.img_q[k][1], T.img_q[k][2], T.img_q[k][3]};      // (scalar loads, once per thread)
+#pragma unroll
+    for (int y = 0; y < kSlotQuarters; ++y)
+      if (y < nq) {
+        const float4 v = *reinterpret_cast<const float4*>(ub + row[y] * stride + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
     *reinterpret_cast<float4*>(U + (int64_t)img * u_stride + i) = a;     // rows are padded to whole 256-ray tiles: the tail past R is scratch
     m = a.x;
     if (i + 1 < R) m = fmaxf(m, a.y);

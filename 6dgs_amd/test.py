@@ -395,7 +395,7 @@ def test_pose_estimation(
                         ev = torch.cuda.Event()
                         ev.record(ps.image_stream)
                     else:
-                        imgs = [torch.from_numpy(np.ascontiguousarray(np.asarray(c.image))).to(dev) for c in cams]
+                        imgs = [torch.from_numpy(np.ascontiguousarray(np.array(c.image))).to(dev) for c in cams]
                 if token_override is not None:
                     torch.cuda.current_stream().wait_event(ev)
                     for t in toks + [up, gt]:
