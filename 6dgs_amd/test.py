@@ -77,14 +77,17 @@ def prepare_images_device(images):
 
 
 class _ImageSideGraph:
-    """hipGraph of the image side of a batch (uint8 -> fp32, resize / crop / normalise, ViT-S/14, token assembly, camera-up
-    CNN): ~250 small launches that are launch-bound at 1..16 images.  One graph per (module weights, batch shape); inputs are
-    copied into a static buffer, outputs are static tensors consumed in stream order before the next replay."""
+    """hipGraphs of the image side of a batch: (a) uint8 -> fp32, resize / crop / normalise, ViT-S/14, token assembly; (b) the camera-up CNN on
+    (a)'s feature maps -- ~250 small launches that are launch-bound at 1..16 images.  One pair per (module weights, batch shape); inputs are
+    copied into a static buffer, outputs are static tensors consumed in stream order before the next replay.  Two graphs because the tokens
+    are needed at the START of the scorer and the camera-up vector only by the pose solve at its END: the pipeline (PoseStream) takes the CNN
+    off the path to the sweep (`defer_cnn`)."""
 
     def __init__(self):
-        self.key, self.graph, self.inp, self.out, self.failed = None, None, None, None, False
+        self.key, self.g_vit, self.g_cnn, self.inp, self.tokens, self.fmaps, self.up, self.failed = None, None, None, None, None, None, None, False
 
-    def run(self, id_module, images):
+    def run(self, id_module, images, defer_cnn: bool = False):
+        """-> (tokens, up), or (tokens, None) with defer_cnn (then `cnn()` replays the second graph); None when the batch cannot be captured."""
         if self.failed or len(images) < 1 or not all(im.shape == images[0].shape and im.shape[-1] == 3 and im.dtype == torch.uint8 for im in images):
             return None
         key = (len(images), tuple(images[0].shape), str(images[0].device), next(id_module.parameters()).data_ptr(),
@@ -96,24 +99,36 @@ class _ImageSideGraph:
                 side = torch.cuda.Stream()
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):               # warm-up on a side stream (lazy initialisation, allocator)
-                    self._body(id_module)
+                    id_module.camera_up(self._vit(id_module)[1])
                 cur.wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.out = self._body(id_module)
-                self.graph, self.key = g, key
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self.tokens, self.fmaps = self._vit(id_module)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self.up = id_module.camera_up(self.fmaps)
+                if isinstance(self.tokens, (list, tuple)):   # ragged tokens (cannot happen for RGB views of one size): not a static output
+                    raise RuntimeError("ragged tokens")
+                self.g_vit, self.g_cnn, self.key = g1, g2, key
             else:
                 torch.stack(list(images), out=self.inp)
-            self.graph.replay()
-            return self.out
+            self.g_vit.replay()
+            if defer_cnn:
+                return self.tokens, None
+            self.g_cnn.replay()
+            return self.tokens, self.up
         except Exception:                                   # capture unsupported (e.g. a backbone with host syncs): stay eager
-            self.failed, self.key, self.graph = True, None, None
+            self.failed, self.key, self.g_vit, self.g_cnn = True, None, None, None
             return None
 
-    def _body(self, id_module):
+    def cnn(self):
+        """The camera-up CNN on the feature maps of the last `run(..., defer_cnn=True)`."""
+        self.g_cnn.replay()
+        return self.up
+
+    def _vit(self, id_module):
         imgs_f, masks = prepare_images_device(list(self.inp))
-        tokens, fmaps = id_module.image_tokens(imgs_f, masks)
-        return tokens, id_module.camera_up(fmaps)
+        return id_module.image_tokens(imgs_f, masks)
 
 
 @torch.no_grad()
@@ -156,6 +171,11 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
         idx, weights, scores = id_module.score_tokens(tokens, rays_ori, rays_dirs, rays_rgb, k, want_scores=want_scores,
                                                       workspace=workspace, images_in_flight=images_in_flight, profile=profile,
                                                       defer_status=defer_status)
+    return _solve_batch(id_module, idx, weights, scores, tokens, up, rays_ori, rays_dirs, gt_c2w, defer_status)
+
+
+def _solve_batch(id_module, idx, weights, scores, tokens, up, rays_ori, rays_dirs, gt_c2w, defer_status):
+    """The end of a batch: pose solve on the selected rays; with defer_status the select statuses ride along with the poses (`packed`)."""
     sol = ops.solve_pose(rays_ori, rays_dirs, idx, weights, up, gt_c2w)
     sol.update(idx=idx, weights=weights, scores=scores, tokens=tokens, up=up)
     if defer_status:
@@ -224,23 +244,35 @@ class PoseStream:
             self._fence = fence
             with torch.cuda.stream(side):
                 cache = self.idm.__dict__.setdefault("_image_side_graph", _ImageSideGraph())
-                res = cache.run(self.idm, images)
-                if res is not None and not isinstance(res[0], (list, tuple)):
-                    # the graph's outputs are STATIC buffers, rewritten by the next replay: this batch keeps its own copy (1.6 MB at 4 images)
-                    tk, u = res
+                res = cache.run(self.idm, images, defer_cnn=True)
+                if res is not None:
+                    # the graphs' outputs are STATIC buffers, rewritten by the next replay: this batch keeps its own copies (1.6 MB at 4 images).
+                    # The tokens are ready when the ViT graph is; the camera-up CNN (needed only by the pose solve at the END of the batch) is replayed
+                    # behind them and no longer sits on the path to the sweep
+                    tk = res[0]
                     tokens = type(tk)(tk.feats.clone(), tk.pe) if hasattr(tk, "feats") else tk.clone()
-                    up = u.clone()
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    up = cache.cnn().clone()
+                    up_ready = torch.cuda.Event()
+                    up_ready.record(side)
                 else:
                     imgs_f, masks = prepare_images_device(images)
                     tokens, fmaps = self.idm.image_tokens(imgs_f, masks)
                     up = self.idm.camera_up(fmaps)
-                ready = torch.cuda.Event()
-                ready.record(side)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    up_ready = ready
             main.wait_event(ready)
             for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))) + [up]:
                 t.record_stream(main)          # allocated on the image stream, read on the caller's
-        sol = estimate_poses(self.idm, None, *self.rays, gt_c2w=gt_c2w, k=self.k, workspace=self.workspace, images_in_flight=self.images_in_flight,
-                             profile=profile, tokens=tokens, up=up, defer_status=True)
+        else:
+            up_ready = None
+        idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
+                                                     images_in_flight=self.images_in_flight, profile=profile, defer_status=True)
+        if up_ready is not None:
+            main.wait_event(up_ready)
+        sol = _solve_batch(self.idm, idx, weights, scores, tokens, up, self.rays[0], self.rays[1], gt_c2w, True)
         # the batch's ONE D2H, behind an event instead of a device sync: [c2w (16) | select status | solve status | t err | ang err | mean kept weight | kept]
         full = torch.cat([sol["packed"], sol["status"].to(torch.float32)[:, None], sol["errors"].to(torch.float32),
                           (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1))[:, None], sol["n_kept"].to(torch.float32)[:, None]], dim=1)

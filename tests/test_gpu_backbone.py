@@ -136,7 +136,7 @@ def test_gpu_image_side_graph_equals_the_eager_per_image_path(syn):
         assert tp.prime_image_graph(idm, images), "the image side did not capture into a hipGraph"
         cache = idm.__dict__["_image_side_graph"]
         tokens, up = cache.run(idm, images)
-        assert cache.graph is not None and not cache.failed
+        assert cache.g_vit is not None and cache.g_cnn is not None and not cache.failed          # two graphs: ViT (tokens, feature maps) and camera-up CNN
         dense = tokens.dense() if hasattr(tokens, "dense") else tokens
         for i, im in enumerate(images):
             img, _ = tp.prepare_image_device(im)
