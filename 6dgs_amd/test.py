@@ -83,8 +83,16 @@ class _ImageSideGraph:
     are needed at the START of the scorer and the camera-up vector only by the pose solve at its END: the pipeline (PoseStream) takes the CNN
     off the path to the sweep (`defer_cnn`)."""
 
+    MAX_ENTRIES = 4         # batch shapes kept: an evaluation's balanced batches come in two sizes per scene (19 views: 10 + 9), a sweep in a few more
+
     def __init__(self):
         self.key, self.g_vit, self.g_cnn, self.inp, self.tokens, self.fmaps, self.up, self.failed = None, None, None, None, None, None, None, False
+        self.entries = {}       # key -> (g_vit, g_cnn, inp, tokens, fmaps, up), most recently used last
+
+    def _activate(self, key):
+        self.g_vit, self.g_cnn, self.inp, self.tokens, self.fmaps, self.up = self.entries[key]
+        self.entries[key] = self.entries.pop(key)
+        self.key = key
 
     def run(self, id_module, images, defer_cnn: bool = False):
         """-> (tokens, up), or (tokens, None) with defer_cnn (then `cnn()` replays the second graph); None when the batch cannot be captured."""
@@ -93,7 +101,10 @@ class _ImageSideGraph:
         key = (len(images), tuple(images[0].shape), str(images[0].device), next(id_module.parameters()).data_ptr(),
                tuple(p._version for p in id_module.parameters()))
         try:
-            if self.key != key:
+            if self.key != key and key in self.entries:
+                self._activate(key)
+                torch.stack(list(images), out=self.inp)
+            elif self.key != key:
                 self.inp = torch.stack(list(images))
                 cur = torch.cuda.current_stream()
                 side = torch.cuda.Stream()
@@ -110,6 +121,10 @@ class _ImageSideGraph:
                 if isinstance(self.tokens, (list, tuple)):   # ragged tokens (cannot happen for RGB views of one size): not a static output
                     raise RuntimeError("ragged tokens")
                 self.g_vit, self.g_cnn, self.key = g1, g2, key
+                self.entries = {k: v for k, v in self.entries.items() if k[3:] == key[3:]}      # graphs of other weights are stale
+                self.entries[key] = (g1, g2, self.inp, self.tokens, self.fmaps, self.up)
+                while len(self.entries) > self.MAX_ENTRIES:
+                    self.entries.pop(next(iter(self.entries)))
             else:
                 torch.stack(list(images), out=self.inp)
             self.g_vit.replay()
@@ -118,7 +133,7 @@ class _ImageSideGraph:
             self.g_cnn.replay()
             return self.tokens, self.up
         except Exception:                                   # capture unsupported (e.g. a backbone with host syncs): stay eager
-            self.failed, self.key, self.g_vit, self.g_cnn = True, None, None, None
+            self.failed, self.key, self.g_vit, self.g_cnn, self.entries = True, None, None, None, {}
             return None
 
     def cnn(self):
