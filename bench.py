@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--scenes", default="", help="cfg5-standin: comma-separated substrings of the scene names to run (default: all twelve)")
     ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
     ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
+    ap.add_argument("--masked-batch", type=int, default=32,
+                    help="cfg5-standin: images per step of a MASKED resident scene (views keep 50-180 of 256 tokens: 2.3 quarters of 64 on average, so 32 views fill "
+                         "19 tiles where 2 x 16 views fill 20; the reference scores one image at a time, the cut is free)")
     ap.add_argument("--streamed-batch", type=int, default=32, help="cfg5-standin: images per step of a streamed scene (one pass of the ray MLP serves them all)")
     ap.add_argument("--no-arena", action="store_true", help="cfg5-standin: big per-scene buffers from PyTorch's caching allocator with empty_cache() between scenes (round 4) instead of one arena")
     ap.add_argument("--stream-above-rays", type=int, default=0,

@@ -109,7 +109,7 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
             torch.cuda.empty_cache()
         lap("release_previous_scene")
         budget = arena.capacity if arena_on else 0.85 * hbm
-        resident = R * 1536 + R // 8 * 96 + ops.ray_keys_workspace_bytes(R, ops.RAY_KEYS_CHUNK_MIN) + 24 * R * min(args.batch, max(n_views, 1)) < 0.97 * budget
+        resident = R * 1536 + R // 8 * 96 + ops.ray_keys_workspace_bytes(R, ops.RAY_KEYS_CHUNK_MIN) + 24 * R * min(getattr(args, "masked_batch", args.batch) if masked else args.batch, max(n_views, 1)) < 0.97 * budget
         if getattr(args, "stream_above_rays", 0) and R > args.stream_above_rays:
             resident = False
         kprof = ops.KernelProfile()
@@ -128,7 +128,7 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         images = [torch.from_numpy(c["image"]).to(dev) for c in cams]
         gts = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams]).to(dev) if cams else None
         lap("views_upload")
-        batch = max(1, min(len(images), args.batch if resident else args.streamed_batch))
+        batch = max(1, min(len(images), (getattr(args, "masked_batch", args.batch) if masked else args.batch) if resident else args.streamed_batch))
         if images:                                   # batches of equal size (19 views: 10 + 9, not 16 + 3): a short last batch sweeps at a near-empty launch's efficiency
             batch = -(-len(images) // (-(-len(images) // batch)))
         if not resident and images and not arena_on:
@@ -155,20 +155,37 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         mem0 = (round(torch.cuda.memory_allocated(dev) / 2**30, 1), round(torch.cuda.memory_reserved(dev) / 2**30, 1), round(torch.cuda.mem_get_info(dev)[0] / 2**30, 1))
         step_s = []
         t0 = time.perf_counter()
-        for b0 in range(0, len(images), batch):
-            t_b = time.perf_counter()
-            sol = tp.estimate_poses(idm, images[b0:b0 + batch], ori, dr, rgb, gt_c2w=gts[b0:b0 + batch], profile=prof,
-                                    streamed_chunk_rays=None if resident else args.chunk_rays, defer_status=resident)
-            if "packed" in sol:
-                c2w = tp.resolve_poses(idm, sol, sol["packed"].cpu())
-            else:
-                c2w = sol["c2w"].cpu()
+        def note(sol, c2w):
+            nonlocal first
             tk = sol["tokens"]                                   # a list (ragged: masked views), a dense block or a BatchedTokens: all index per image
-            tok_counts += [int(tk[i].shape[0]) for i in range(len(tk))]
+            tok_counts.extend(int(tk[i].shape[0]) for i in range(len(tk)))
             if first is None:
                 first = {"tokens": tk[0].contiguous().clone(), "up": sol["up"][:1].clone(), "c2w": c2w[0].clone()}
-            step_s.append(round(time.perf_counter() - t_b, 3))
-            del sol
+
+        if resident and not getattr(args, "no_pipeline", False):
+            # resident scenes: two batches in flight (tp.PoseStream), as the evaluation loop of test_pose_estimation runs them; step_s = intervals between completions
+            ps, prev, t_b = tp.PoseStream(idm, ori, dr, rgb), None, time.perf_counter()
+            for b0 in list(range(0, len(images), batch)) + [None]:
+                cur = ps.submit(images[b0:b0 + batch], gts[b0:b0 + batch], profile=prof) if b0 is not None else None
+                if prev is not None:
+                    c2w, sol = ps.collect(prev)
+                    note(sol, c2w)
+                    step_s.append(round(time.perf_counter() - t_b, 3))
+                    t_b = time.perf_counter()
+                    del sol
+                prev = cur
+        else:
+            for b0 in range(0, len(images), batch):
+                t_b = time.perf_counter()
+                sol = tp.estimate_poses(idm, images[b0:b0 + batch], ori, dr, rgb, gt_c2w=gts[b0:b0 + batch], profile=prof,
+                                        streamed_chunk_rays=None if resident else args.chunk_rays, defer_status=resident)
+                if "packed" in sol:
+                    c2w = tp.resolve_poses(idm, sol, sol["packed"].cpu())
+                else:
+                    c2w = sol["c2w"].cpu()
+                note(sol, c2w)
+                step_s.append(round(time.perf_counter() - t_b, 3))
+                del sol
         torch.cuda.synchronize()
         dd.barrier()
         t_eval = dd.max_over_ranks(time.perf_counter() - t0, dev)
