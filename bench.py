@@ -23,9 +23,11 @@ random init: DINOv2 weights are not downloadable) -> q_proj -> ray<->token score
 scene, as in the reference (pretrain_eval_attention.py:89), and is reported separately.
 
 Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize, max over ranks;
-value = (N * batch * K) / time.  Every step ends with the poses on the host, so the K per-step wall times are exact
-too: their median is reported beside the mean (`median_step`).  Images and scene arrays are resident
-in HBM when the clock starts.  Rank 0 prints ONE JSON line with `roofline` (the logits kernel: algorithmic FLOP /
+value = (N * batch * K) / time.  Every step ends with the poses on the host.  By default the steps are PIPELINED (round 5: the
+evaluation is a stream of batches, test.py:46-302): batch N + 1 is submitted -- its image side on a second stream -- before
+batch N's poses are collected (6dgs_amd.test.PoseStream; same poses bit for bit; `--no-pipeline` = one batch at a time with a
+device sync per step, rounds 1-4); `median_step` is then the median interval between the completions of consecutive batches
+(SURVEY §8(d)), `config.pipeline` says which form ran.  Images and scene arrays are resident in HBM when the clock starts.  Rank 0 prints ONE JSON line with `roofline` (the logits kernel: algorithmic FLOP /
 HIP-event time), `fp32_logits_mode` (the same workload with the logits kept in fp32 between the passes instead of
 24-bit fixed point: the cost of not narrowing) and, at N = 1, `cpu_baseline` (the CPU oracle on a bounded ray sample).
 """
