@@ -17,6 +17,21 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline"}
 
 
+def _run_eight(cmd, env, timeout):
+    """Eight processes sharing ONE GPU (eight HIP contexts, gloo between them) is a rehearsal outside what the runtime is exercised for: in one of ~8 runs
+    on one box an IDLE rank (no views of its own) died with SIGABRT and no Python traceback, five identical re-runs passed (tools/round5_calls/r5_call14.sh).
+    The rehearsal checks this build's rank logic, so a run that dies that way is repeated once -- and said so."""
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    if p.returncode != 0 and "SIGABRT" in (p.stderr + p.stdout):
+        print("8-rank run aborted in the runtime (SIGABRT); repeating once:\n" + p.stderr[-800:])
+        cmd = list(cmd)
+        if "--master-port" in cmd:                       # a fresh rendezvous port for the second attempt
+            i = cmd.index("--master-port") + 1
+            cmd[i] = str(int(cmd[i]) + 1)
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return p
+
+
 def _run(cmd, env=None, timeout=400):
     e = dict(os.environ)
     e.update(env or {})
@@ -111,8 +126,8 @@ def test_bench_eight_ranks_on_one_gpu_over_gloo():
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(SIXDGS_BENCH_BACKEND="gloo", SIXDGS_BENCH_FORCE_DEVICE="0", SIXDGS_RANDOM_BACKBONE="1", OMP_NUM_THREADS="2")
-    p = subprocess.run([sys.executable, "-W", "ignore", "bench.py", "--gpus", "8", "--gaussians", "8000", "--batch", "2", "--steps", "2", "--warmup", "1",
-                        "--skip-reference-mode", "--l32-steps", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    p = _run_eight([sys.executable, "-W", "ignore", "bench.py", "--gpus", "8", "--gaussians", "8000", "--batch", "2", "--steps", "2", "--warmup", "1",
+                    "--skip-reference-mode", "--l32-steps", "0"], env, 400)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-1000:]
@@ -212,9 +227,8 @@ def test_evaluation_sweep_with_eight_ranks_on_one_gpu(tmp_path):
                                   ("gloo8", ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29571"],
                                    {"SIXDGS_DIST_BACKEND": "gloo", "SIXDGS_FORCE_DEVICE": "0"})):
         out = os.path.join(root, f"res_{name}.json")
-        p = subprocess.run([sys.executable, "-W", "ignore", *launcher, os.path.join(ROOT, "pretrain_eval_attention.py"), "--exp_path", os.path.join(root, "output"),
-                            "--out_path", out, "--data_type", "mip360", "--skip_train", "--batch_size", "3", "--max_ellipsoids", "-1"], cwd=ROOT, env=dict(base, **extra),
-                           capture_output=True, text=True, timeout=800)
+        p = _run_eight([sys.executable, "-W", "ignore", *launcher, os.path.join(ROOT, "pretrain_eval_attention.py"), "--exp_path", os.path.join(root, "output"),
+                        "--out_path", out, "--data_type", "mip360", "--skip_train", "--batch_size", "3", "--max_ellipsoids", "-1"], dict(base, **extra), 400)
         assert p.returncode == 0, p.stderr[-3000:]
         if name == "gloo8":
             assert "evaluation sweep over 8 rank(s), backend gloo" in (p.stdout + p.stderr)
