@@ -385,23 +385,24 @@ def score_select_ray_sharded(q: torch.Tensor, n_tok: torch.Tensor, key_planes: t
 
     r_local = key_planes.shape[0]
     cmax = ops.SELECT_MAX_CANDIDATES if max_candidates is None else int(max_candidates)
-    ss = ops.SelectStream(q, n_tok, r_local, topk, cmax, n_tok_host)
-    stats = merge_row_stats(ss.sample_stats(sample_planes, sample_scale), group)             # identical ctok on every rank
-    ss.prepare(stats, r_sample_total, r_total)
-    if key_norm is not None:                    # max |k_r| of the local planes, kept beside them (otherwise: one more pass over the planes)
-        ss.key_norm.copy_(key_norm)
-    ss.sweep(key_planes, key_scale, 0, profile, update_norm=key_norm is None)
-    _all_reduce(ss.gsum, dist.ReduceOp.SUM, group)                                            # exact g_t over ALL rays
-    _all_reduce(ss.key_norm, dist.ReduceOp.MAX, group)
-    # U_(k) of the scene from the ranks' exact k largest U.  (The single-GPU path takes a lower bound from the tile maxima of U and repairs the
-    # rare image whose top rays sit in a few tiles on the device; here that repair would be a second round of collectives, and six passes over
-    # the local U are 1 % of a rank's sweep.)
-    uk = kth_largest_of_union(ss.topk_u(exact=True), min(topk, r_total), group)
-    cand, count = ss.candidates(uk=uk)
-    idx, val, status = ss.rescore(key_planes, key_scale, cand, count, compact=False, allow_fewer=True)
-    st = status.to(torch.int64)
-    bad = _all_reduce((st < 0).to(torch.int64), dist.ReduceOp.MAX, group) if is_dist() else (st < 0).to(torch.int64)
-    tot = _all_reduce(st.clamp(min=0), dist.ReduceOp.SUM, group) if is_dist() else st.clamp(min=0)
+    with ops.arena_scope():      # U and the stage workspace of this batch go back to the arena (if one is installed) when the batch is enqueued
+        ss = ops.SelectStream(q, n_tok, r_local, topk, cmax, n_tok_host)
+        stats = merge_row_stats(ss.sample_stats(sample_planes, sample_scale), group)             # identical ctok on every rank
+        ss.prepare(stats, r_sample_total, r_total)
+        if key_norm is not None:                    # max |k_r| of the local planes, kept beside them (otherwise: one more pass over the planes)
+            ss.key_norm.copy_(key_norm)
+        ss.sweep(key_planes, key_scale, 0, profile, update_norm=key_norm is None)
+        _all_reduce(ss.gsum, dist.ReduceOp.SUM, group)                                            # exact g_t over ALL rays
+        _all_reduce(ss.key_norm, dist.ReduceOp.MAX, group)
+        # U_(k) of the scene from the ranks' exact k largest U.  (The single-GPU path takes a lower bound from the tile maxima of U and repairs the
+        # rare image whose top rays sit in a few tiles on the device; here that repair would be a second round of collectives, and six passes over
+        # the local U are 1 % of a rank's sweep.)
+        uk = kth_largest_of_union(ss.topk_u(exact=True), min(topk, r_total), group)
+        cand, count = ss.candidates(uk=uk)
+        idx, val, status = ss.rescore(key_planes, key_scale, cand, count, compact=False, allow_fewer=True)
+        st = status.to(torch.int64)
+        bad = _all_reduce((st < 0).to(torch.int64), dist.ReduceOp.MAX, group) if is_dist() else (st < 0).to(torch.int64)
+        tot = _all_reduce(st.clamp(min=0), dist.ReduceOp.SUM, group) if is_dist() else st.clamp(min=0)
     gidx, gval = merge_topk(idx, val, ray_offset, topk, group)
     out_status = torch.where(bad > 0, torch.full_like(tot, -1), tot).tolist()
     for b, v in enumerate(out_status):

@@ -129,7 +129,7 @@ class IdentificationModule(torch.nn.Module):
             self._key_cache = self._key_cache_rays = None        # drop the old planes before allocating the new ones
             if ops.get_arena() is not None:                      # ... and with an arena everything else that was carved from it for the old scene
                 self._select_ws = self._stream_sample = None
-                ops.get_arena().reset()
+                ops.get_arena().reset(self)
             r = rays_ori.shape[0]
             planes_mode = mode != ops.MMA_F32
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
@@ -210,7 +210,7 @@ class IdentificationModule(torch.nn.Module):
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
         self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = self._peq = None
         if ops.get_arena() is not None:       # the planes / workspaces just dropped were carved from it (an arena serves ONE module: ops.Arena)
-            ops.get_arena().reset()
+            ops.get_arena().reset(self)
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
@@ -378,7 +378,7 @@ class IdentificationModule(torch.nn.Module):
                 self._stream_sample = held = None
                 if ops.get_arena() is not None:                  # a new scene: what the arena held for the previous one goes
                     self._key_cache = self._key_cache_rays = self._select_ws = None
-                    ops.get_arena().reset()
+                    ops.get_arena().reset(self)
                 si = ops.select_sample_indices(r, dev)
                 _, _, (sp, sscale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)
                 self._stream_sample = held = (ident, (rays_ori, rays_dir, rays_rgb), sp, sscale)      # once per scene, like the key cache
@@ -408,59 +408,70 @@ class IdentificationModule(torch.nn.Module):
                 i2, v2 = self.score_tokens_streamed(sub, rays_ori, rays_dir, rays_rgb, k, chunk_rays, profile, key_cache_bytes, use_select=False)
                 sel = torch.tensor(redo, device=dev)
                 idx[sel], val[sel] = i2, v2
+                self.last_scoring_path = f"streamed select+two-pass({len(redo)})"       # (the inner call left "streamed two-pass")
             return idx, val
-        ws = torch.empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), dtype=torch.uint8, device=dev)
-        if key_cache_bytes is None:
-            # 70 % of what is free once the transient needs of ONE chunk are set aside: its key planes (they exist while the chunk is
-            # scored, kept or not) and the ray-MLP workspace of sixdgs_ray_keys_ex
+        # Streamed two-pass.  With an arena installed the scene is streamed BECAUSE its planes exceed the arena: everything taken here is scoped
+        # (the chunks' planes used to be carved in both sweeps and never given back -> "arena exhausted" on the refused image of a
+        # streamed scene) -- the logits workspace and the planes KEPT from sweep 1 to sweep 2 live until the end of the call, a chunk that is not
+        # kept gives its planes back as soon as its pass is enqueued (reuse is ordered by the stream).
+        with ops.arena_scope():
+            ws = ops.big_empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), torch.uint8, dev)
             n_c = min(chunk, r)
-            transient = n_c * (1536 if f16 else (2304 if planes_mode else 4 * ops.D)) + int(_lib_ray_keys_ws(n_c))
-            key_cache_bytes = max(0, int(0.7 * (torch.cuda.mem_get_info(dev)[0] - transient)))
-        kept, kept_bytes = {}, 0                                                  # r0 -> key operand of the chunk, sweep 1 -> sweep 2
+            per_ray = 1536 if f16 else (2304 if planes_mode else 4 * ops.D)
+            if key_cache_bytes is None:
+                # 70 % of what is free once the transient needs of ONE chunk are set aside: its key planes (they exist while the chunk is
+                # scored, kept or not) and the ray-MLP workspace of sixdgs_ray_keys_ex.  "Free" is the arena's room when the planes come from it.
+                transient = n_c * per_ray + int(_lib_ray_keys_ws(n_c, ops.RAY_KEYS_CHUNK_MIN if ops.get_arena() is not None else ops.RAY_KEYS_CHUNK))
+                arena = ops.get_arena()
+                from_arena = arena is not None and planes_mode and arena.buf.device == dev
+                room = (arena.capacity - arena.mark()) if from_arena else torch.cuda.mem_get_info(dev)[0]
+                key_cache_bytes = max(0, int(0.7 * (room - transient)))
+            kept, kept_bytes = {}, 0                                                  # r0 -> key operand of the chunk, sweep 1 -> sweep 2
 
-        def chunk_keys(r0, may_keep):
-            nonlocal kept_bytes
-            if r0 in kept:
-                return kept.pop(r0)
-            r1 = min(r0 + chunk, r)
-            o, d, c = rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1]             # row slices of contiguous [R,3]: contiguous views
-            if not planes_mode:
-                _, key = ops.ray_keys(o, d, c, w)
-                ent, nbytes = (key, None, None), key.numel() * 4
-            else:
+            def chunk_keys(r0):
+                r1 = min(r0 + chunk, r)
+                o, d, c = rays_ori[r0:r1], rays_dir[r0:r1], rays_rgb[r0:r1]             # row slices of contiguous [R,3]: contiguous views
+                if not planes_mode:
+                    _, key = ops.ray_keys(o, d, c, w)
+                    return (key, None, None)
                 _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
                 planes, scale = planes if f16 else (planes, None)
-                ent, nbytes = (None, planes, scale), planes.numel()
-            if may_keep and kept_bytes + nbytes <= key_cache_bytes:
-                kept[r0], kept_bytes = ent, kept_bytes + nbytes
-            return ent
+                return (None, planes, scale)
 
-        def chunk_pass1(r0, may_keep):
-            key, planes, scale = chunk_keys(r0, may_keep)
-            return ops.score_pass1(q, n_tok, key, ws, k, key_planes=planes, key_scale=scale, profile=profile, n_tok_host=n_host)
+            def chunk_pass1(r0, may_keep):
+                nonlocal kept_bytes
+                run = lambda ent: ops.score_pass1(q, n_tok, ent[0], ws, k, key_planes=ent[1], key_scale=ent[2], profile=profile, n_tok_host=n_host)
+                if r0 in kept:
+                    return run(kept.pop(r0))
+                nbytes = (min(r0 + chunk, r) - r0) * per_ray
+                if may_keep and kept_bytes + nbytes <= key_cache_bytes:
+                    kept[r0], kept_bytes = chunk_keys(r0), kept_bytes + nbytes         # stays taken until the call's scope ends
+                    return run(kept[r0])
+                with ops.arena_scope():                                                 # one chunk's planes, given back when its pass is enqueued
+                    return run(chunk_keys(r0))
 
-        m_g = torch.full((b, ops.MAX_TOKENS), -float("inf"), device=dev)
-        s_g = torch.zeros(b, ops.MAX_TOKENS, device=dev)
-        for r0 in range(0, r, chunk):                        # sweep 1: statistics
-            st = chunk_pass1(r0, True)
-            m_c, s_c = st[..., 0], st[..., 1]
-            m_n = torch.maximum(m_g, m_c)
-            safe = torch.where(torch.isinf(m_n), torch.zeros_like(m_n), m_n)
-            s_g = s_g * torch.exp(torch.where(torch.isinf(m_g), torch.full_like(m_g, -float("inf")), m_g - safe)) + \
-                s_c * torch.exp(torch.where(torch.isinf(m_c), torch.full_like(m_c, -float("inf")), m_c - safe))
-            m_g = m_n
-        glob = torch.stack([m_g, s_g], dim=-1).contiguous()
-        best_i = torch.full((b, k), -1, dtype=torch.int64, device=dev)
-        best_v = torch.full((b, k), float("nan"), device=dev)
-        mass = torch.zeros(b, dtype=torch.float64, device=dev)
-        from . import distributed as dd
-        for r0 in range(0, r, chunk):                        # sweep 2: scores of the chunk, candidate merge
-            chunk_pass1(r0, False)
-            idx, val, sc = ops.score_pass2(glob, n_tok, min(r0 + chunk, r) - r0, ws, k, used_planes=planes_mode, want_scores=return_stats)
-            if return_stats:
-                mass += sc.double().sum(dim=1)
-            gi = torch.where(idx >= 0, idx + r0, idx)
-            best_i, best_v = dd.merge_topk(torch.cat([best_i, gi], dim=1), torch.cat([best_v, val], dim=1), 0, k, group=False)
+            m_g = torch.full((b, ops.MAX_TOKENS), -float("inf"), device=dev)
+            s_g = torch.zeros(b, ops.MAX_TOKENS, device=dev)
+            for r0 in range(0, r, chunk):                        # sweep 1: statistics
+                st = chunk_pass1(r0, True)
+                m_c, s_c = st[..., 0], st[..., 1]
+                m_n = torch.maximum(m_g, m_c)
+                safe = torch.where(torch.isinf(m_n), torch.zeros_like(m_n), m_n)
+                s_g = s_g * torch.exp(torch.where(torch.isinf(m_g), torch.full_like(m_g, -float("inf")), m_g - safe)) + \
+                    s_c * torch.exp(torch.where(torch.isinf(m_c), torch.full_like(m_c, -float("inf")), m_c - safe))
+                m_g = m_n
+            glob = torch.stack([m_g, s_g], dim=-1).contiguous()
+            best_i = torch.full((b, k), -1, dtype=torch.int64, device=dev)
+            best_v = torch.full((b, k), float("nan"), device=dev)
+            mass = torch.zeros(b, dtype=torch.float64, device=dev)
+            from . import distributed as dd
+            for r0 in range(0, r, chunk):                        # sweep 2: scores of the chunk, candidate merge
+                chunk_pass1(r0, False)
+                idx, val, sc = ops.score_pass2(glob, n_tok, min(r0 + chunk, r) - r0, ws, k, used_planes=planes_mode, want_scores=return_stats)
+                if return_stats:
+                    mass += sc.double().sum(dim=1)
+                gi = torch.where(idx >= 0, idx + r0, idx)
+                best_i, best_v = dd.merge_topk(torch.cat([best_i, gi], dim=1), torch.cat([best_v, val], dim=1), 0, k, group=False)
         if return_stats:
             return best_i, best_v, glob, mass
         return best_i, best_v

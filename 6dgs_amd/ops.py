@@ -404,6 +404,7 @@ class Arena:
     def __init__(self, nbytes: int, device):
         self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         self.off, self.high = 0, 0
+        self._owner = None          # weakref to the ONE module whose per-scene buffers live here (reset(owner) claims it)
 
     @property
     def capacity(self) -> int:
@@ -424,8 +425,21 @@ class Arena:
     def release(self, mark: int) -> None:
         self.off = int(mark)
 
-    def reset(self) -> None:
+    def reset(self, owner=None) -> None:
+        """Everything carved so far is handed out again.  `owner`: the module doing so -- an arena serves ONE IdentificationModule at a time (its key planes,
+        workspaces and sample are dropped by that module before it resets); a reset by a second LIVE module while the first still exists would hand the
+        first one's planes out again under its feet, so it is refused.  `release_owner()` passes the arena on."""
+        if owner is not None:
+            cur = self._owner() if self._owner is not None else None
+            if cur is not None and cur is not owner:
+                raise RuntimeError("6dgs_amd: this arena already serves another IdentificationModule (ops.Arena serves one module at a time: "
+                                   "call arena.release_owner() once the first module's scene is done, or give the second module its own arena)")
+            import weakref
+            self._owner = weakref.ref(owner)
         self.off = 0
+
+    def release_owner(self) -> None:
+        self._owner = None
 
 
 _arena: Optional[Arena] = None

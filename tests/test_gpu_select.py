@@ -485,3 +485,37 @@ def test_sweep_launch_grouping_is_invisible(ops, tmp_path):
     for i in (1, 9, 13):
         idx, val, st = ops.score_select(c["q"][i:i + 1].contiguous(), c["nt"][i:i + 1].contiguous(), c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100, max_candidates=4096)
         assert np.array_equal(idx.cpu().numpy()[0], a["idx"][i]) and int(st[0]) == int(a["status"][i])
+
+
+def test_streamed_scene_with_an_arena_survives_a_refused_image(ops, syn):
+    """with an arena installed a scene is streamed BECAUSE its planes exceed the arena -- the two-pass fallback of the streamed select path
+    (a refused image) used to carve every chunk's planes from the arena in both sweeps without giving them back and died with "arena exhausted".  Here:
+    an arena that holds ~2.3 chunks of planes, a 1.3 M-ray scene streamed in chunks of 2^18 rays (6 chunks, two sweeps), every image refused (room for 104
+    candidates under a flat softmax) -> the answer is the two-pass scorer's, the arena is back at its mark, and the same call works again."""
+    pkg = importlib.import_module("6dgs_amd")
+    idm = pkg.IdentificationModule("dino")
+    idm.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_scorer_state_dict(0).items()}, strict=False)
+    idm = idm.cuda().eval()
+    rays = syn.make_rays(1_300_000, 2)
+    o, d, c = (torch.from_numpy(rays[k]).cuda() for k in ("ori", "dir", "rgb"))
+    flat = [torch.from_numpy(syn.make_tokens(t, 30 + i, 40.0)).cuda() * 0.0005 for i, t in enumerate((256, 173))]
+    chunk = 1 << 18
+    i_ref, v_ref = idm.score_tokens_streamed(flat, o, d, c, 100, chunk_rays=chunk, use_select=False)          # torch's allocator: the reference answer
+    need_ws = ops.score_topk_workspace_bytes(chunk, 2, 100, planes=True)
+    arena = ops.Arena(need_ws + int(2.3 * chunk * 1536) + ops.ray_keys_workspace_bytes(chunk, ops.RAY_KEYS_CHUNK_MIN) + (1300000 // 16 + 256) * 1536 + (64 << 20), "cuda")
+    assert arena.capacity < 1_300_000 * 1536            # the scene's planes do NOT fit: that is why it is streamed
+    old, prev = ops.SELECT_MAX_CANDIDATES, ops.set_arena(arena)
+    try:
+        ops.SELECT_MAX_CANDIDATES = 104
+        for _ in range(2):
+            i_a, v_a = idm.score_tokens_streamed(flat, o, d, c, 100, chunk_rays=chunk)
+            assert idm.last_scoring_path == "streamed select+two-pass(2)"
+            assert torch.equal(i_a, i_ref) and torch.equal(v_a, v_ref)
+        held = arena.mark()                               # what stays taken between calls: the scene's ray sample, nothing per batch or per chunk
+        i_b, v_b = idm.score_tokens_streamed(flat, o, d, c, 100, chunk_rays=chunk, use_select=False)
+        assert arena.mark() == held and torch.equal(i_b, i_ref)
+        assert arena.high <= arena.capacity
+    finally:
+        ops.SELECT_MAX_CANDIDATES = old
+        ops.set_arena(prev)
+        idm.invalidate_caches()

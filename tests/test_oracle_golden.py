@@ -142,6 +142,29 @@ def test_a13_ray_features_and_keys(scorer_state):
     assert rel_err(key.astype(np.float64).sum(0), g["key_sum"]) < 1e-6
 
 
+def test_linear_is_one_fma_chain_per_output(oracle):
+    """The oracle's dense helper (round 6: a 6 x 16 register tile over packed weight panels) computes every output as ONE chain of fp32
+    FMAs over k in order, then + bias: a row's result may not depend on where the row sits in a tile or a work item (tails included),
+    odd N / K go through the padded panel, and the value is the fp32-FMA chain itself (emulated in float64: a product of two fp32 values
+    is exact there)."""
+    rng = np.random.default_rng(5)
+    m, k, n = 131, 77, 45
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    y = oracle.linear(x, w, b)
+    for lo, hi in ((0, 1), (5, 6), (47, 50), (96, 131), (130, 131)):
+        assert np.array_equal(oracle.linear(x[lo:hi], w, b), y[lo:hi])
+    perm = rng.permutation(m)
+    assert np.array_equal(oracle.linear(x[perm], w, b), y[perm])
+    assert np.array_equal(oracle.linear(x, w, b, relu=True), np.maximum(y, 0))
+    acc = np.zeros((m, n), np.float32)
+    for kk in range(k):          # fma(a, b, c) = round32(a * b + c); a * b is exact in float64, the sum is rounded once to 53 bits, then to 24
+        acc = (x[:, kk:kk + 1].astype(np.float64) * w[:, kk][None, :].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+    ref = acc + b[None, :]
+    assert (y != ref).mean() < 1e-3 and np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()      # (double rounding can flip a last bit, rarely)
+
+
 @pytest.mark.parametrize("tag,T,scale", [("flat256", 256, 1.0), ("peaky256", 256, 40.0), ("peaky137", 137, 40.0),
                                          ("mid1", 1, 10.0)])
 def test_a14_a15_scores_topk(oracle, scorer_state, syn, tag, T, scale):
