@@ -50,13 +50,17 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tup
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = os.environ.get("SIXDGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
+            # device_id: the default group's communicator is created EAGERLY, bound to this rank's GPU -- a rank whose device is wrong
+            # or busy fails here, at init, with every peer at the same point, instead of inside the first collective of an unattended evaluation;
+            # later groups (the long-wait one) are split off it
+            kw["device_id"] = torch.device("cuda", local)
         # The backend's default timeout (10 min with nccl = RCCL, 30 min with gloo) stays on the default group: a rank that dies between
         # two stages takes its peers down within minutes, not hours.  Only the stage one rank may legitimately spend hours in -- the
         # evaluation sweep trains a missing id_module.th on rank 0 (1500 x 32 steps) while the others wait -- gets a long timeout, on
         # its own group (agree(..., long_wait=True)).  SIXDGS_DIST_TIMEOUT_S overrides the default group's timeout (seconds).
-        kw = {}
         if os.environ.get("SIXDGS_DIST_TIMEOUT_S"):
             kw["timeout"] = datetime.timedelta(seconds=int(os.environ["SIXDGS_DIST_TIMEOUT_S"]))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
@@ -64,8 +68,11 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Tup
         # communicator is built lazily on its FIRST collective, where the peers wait for rank 0's unique id in the store under the
         # DEFAULT group's timeout (10 min).  Created inside agree() that first collective came after rank 0's hours of training: the
         # peers timed out in the store long before.  One tiny all-reduce here, while every rank is at the same point, builds it.
+        # With nccl and set_device=False the caller pins the device AFTER this call: every rank is still on device 0 here and a collective
+        # would put them all on one GPU -- such callers run warm_long_wait_group() themselves once the device is pinned.
         _single_rank_group = single
-        warm_long_wait_group(None if backend == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        if backend == "gloo" or set_device:
+            warm_long_wait_group(None if backend == "gloo" else torch.device("cuda", local))
     if single and dist.is_initialized():
         _single_rank_group = True
     return rank, world, local
@@ -75,29 +82,30 @@ def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_group)
 
 
-def long_wait_group():
-    """The process group for collectives a rank may wait hours in (SIXDGS_DIST_LONG_TIMEOUT_S, default 12 h).  init_from_env creates
-    it and runs its first collective (warm_long_wait_group); a process group initialised elsewhere gets it on first use -- collectively,
-    so call warm_long_wait_group() right after init_process_group in that case."""
+def long_wait_group(device=None):
+    """The process group for collectives a rank may wait hours in (SIXDGS_DIST_LONG_TIMEOUT_S, default 12 h).  Creating it is COLLECTIVE and ends in
+    one 4-byte all-reduce on it (`device`: where, for nccl; default the current device), so that its communicator exists on every rank from then on --
+    also when it is re-created because the timeout variable changed (the re-created group used to stay cold, the original bug again).
+    init_from_env does this at start-up; a process group initialised elsewhere, or with set_device=False, gets it through warm_long_wait_group()."""
     global _long_group, _long_group_timeout_s
     t = int(os.environ.get("SIXDGS_DIST_LONG_TIMEOUT_S", str(12 * 3600)))
     if _long_group is None or _long_group_timeout_s != t:
         _long_group = dist.new_group(timeout=datetime.timedelta(seconds=t))
         _long_group_timeout_s = t
+        dev = "cpu" if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=_long_group)
+        if int(one.item()) != dist.get_world_size():
+            raise RuntimeError(f"6dgs_amd: long-wait group saw {int(one.item())} of {dist.get_world_size()} ranks")
     return _long_group
 
 
 def warm_long_wait_group(device=None) -> None:
-    """Create the long-wait group and run one 4-byte all-reduce on it, so that its communicator exists on every rank from now on.
-    Collective: every rank calls it at the same point (init_from_env does)."""
+    """Create the long-wait group (first collective included, see long_wait_group) if it does not exist yet.  Collective: every rank calls it at
+    the same point -- init_from_env does; callers that pin their device themselves (set_device=False with nccl) call it right after."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    g = long_wait_group()
-    dev = "cpu" if dist.get_backend() == "gloo" else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-    one = torch.ones(1, dtype=torch.int32, device=dev)
-    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=g)
-    if int(one.item()) != dist.get_world_size():
-        raise RuntimeError(f"6dgs_amd: long-wait group saw {int(one.item())} of {dist.get_world_size()} ranks")
+    long_wait_group(device)
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -276,6 +284,16 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_floats(x: float, device) -> list:
+    """One float of every rank, in rank order, on every rank (bench.py: each rank's own time next to the max -- which GPU of an 8-GPU node is the slow one)."""
+    if not is_dist():
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [float(b.item()) for b in bufs]
 
 
 # ---------------------------------------------------------------------------------------------

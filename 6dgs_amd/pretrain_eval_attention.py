@@ -170,6 +170,7 @@ def main(argv=None, backbone: Optional[torch.nn.Module] = None) -> List[dict]:
         raise RuntimeError("6dgs_amd: the evaluation sweep needs an MI355X (no CPU fallback on the product path)")
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
+    dd.warm_long_wait_group(torch.device(device))          # (exists already unless init_from_env left it to us: nccl with a forced device)
     if dd.is_dist():
         seen = dd.ranks_seen(torch.device(device))          # a collective: every rank takes part, rank 0 reports
         if rank == 0:

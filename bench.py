@@ -165,6 +165,7 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dd.warm_long_wait_group(dev)              # (exists already unless init_from_env left it to us: nccl with a forced device)
     torch.manual_seed(0)
     if args.config == "cfg5-standin":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -350,7 +351,7 @@ def main():
     # and the image side of N + 1 (own stream) overlaps the small serial kernels behind sweep N.  Every batch still ends with its poses on the host.
     pipelined = bool(use_select and not args.graph and not args.no_pipeline and not ray_sharded and not streamed)
     ps = tp.PoseStream(idm, ori, dr, rgb, workspace=ws) if pipelined else None
-    last_host = [None]
+    last_host, rank_s = [None], [0.0]
 
     def timed(n_steps, p):
         """exactly n_steps steps bracketed by barrier + synchronize; (max-over-ranks seconds, per-step seconds, last results).  Pipelined: per-step
@@ -383,6 +384,7 @@ def main():
                     host = allp.cpu().view(world, n_steps, args.batch, 4, 4)[:, -1].reshape(-1, 4, 4)
             last_host[0] = host
         torch.cuda.synchronize()
+        rank_s[0] = time.perf_counter() - t_begin          # this rank's own time for its n_steps steps (before the closing barrier)
         dd.barrier()
         return dd.max_over_ranks(time.perf_counter() - t_begin, dev), per, s
 
@@ -391,6 +393,7 @@ def main():
         if ps is not None and use_select and ops.select_enabled():      # ... and through the pipelined path itself (its stream, its first graph replay there, its pinned buffers)
             ps.collect(ps.submit(images, gts))
     elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
+    per_rank_s = dd.all_floats(rank_s[0], dev)          # every rank's own time for the K steps: the line names the slowest rank
     if args.graph:        # HIP events cannot be read out of a captured graph: the kernel's duration comes from a few EAGER steps of the same batch
         g_keep, graph = graph, None
         for _ in range(min(args.steps, 5)):
@@ -462,6 +465,7 @@ def main():
             "mma": mma_name[mode],
         },
         "ranks_seen": ranks_seen, "backend": dd.backend_name(),
+        "per_rank_ms_per_step": [round(1e3 * t / args.steps, 3) for t in per_rank_s], "slowest_rank": int(max(range(len(per_rank_s)), key=per_rank_s.__getitem__)),
         "scene_setup_s": {"total": round(t_setup, 3), "breakdown": setup_items,
                           "standin": round(sum(v for k_, v in setup_items.items() if k_.startswith("standin_")), 3), "normals+emission": round(t_emit, 3), "key_plane_buffer_alloc": round(t_alloc, 3),
                           "ray_mlp_keys": round(t_keys, 3), "ray_mlp_keys_kernels": round(k_ms * 1e-3, 3),

@@ -225,6 +225,9 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
                 "top100_identical_select": bool(set(i1[0].tolist()) == set(oi.tolist())),
                 "value_rel_err_select": float(np.abs(v1[0].cpu().numpy() - s[i1[0].cpu().numpy()]).max() / s.max()),
                 "pose_rel_err": float(np.abs(solp["c2w"][0].cpu().numpy() - p_ref["c2w"]).max() / scale),
+                # the metric's own error measures (error_computation.py:3-8) between the HIP pose and the ORACLE's pose of the same view
+                "rot_err_deg_vs_oracle": float(np.degrees(np.arccos(np.clip((np.trace(solp["c2w"][0, :3, :3].cpu().numpy().astype(np.float64) @ p_ref["c2w"][:3, :3].astype(np.float64).T) - 1.0) / 2.0, -1.0, 1.0)))),
+                "trans_err_vs_oracle": float(np.linalg.norm(solp["c2w"][0, :3, 3].cpu().numpy().astype(np.float64) - p_ref["c2w"][:3, 3].astype(np.float64))),
                 "oracle_s": {"ray_mlp": round(t_mlp, 2), "scorer_topk_pose": round(t_pose, 2)}}
             if cpu_sample is None:
                 cpu_sample = (rs, R, t_mlp, t_pose, name)
@@ -262,7 +265,9 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
         "parity_summary": {"scenes_checked": len(ok),
                            "all_top100_identical": bool(ok) and all(p["top100_identical_two_pass"] and p["top100_identical_select"] for p in ok),
                            "max_score_rel_err": max((p["score_rel_err"] for p in ok), default=None),
-                           "max_pose_rel_err": max((p["pose_rel_err"] for p in ok), default=None)},
+                           "max_pose_rel_err": max((p["pose_rel_err"] for p in ok), default=None),
+                           "mean_rot_err_deg_vs_oracle": float(np.mean([p["rot_err_deg_vs_oracle"] for p in ok])) if ok else None,
+                           "mean_trans_err_vs_oracle": float(np.mean([p["trans_err_vs_oracle"] for p in ok])) if ok else None},
         "roofline": {"kernel": "k_logits_f16x<UB> (select sweep) over all scenes", "bound": "mfma", "achieved": round(sweep_fl / (sweep_ms * 1e-3) / 1e12, 2) if sweep_ms > 0 else None,
                      "peak": round(peak_tflops / 3, 1), "unit": "TFLOP/s", "frac": round(sweep_fl / (sweep_ms * 1e-3) / 1e12 / (peak_tflops / 3), 4) if sweep_ms > 0 else None,
                      "traffic": None, "launches": sweep_n,
