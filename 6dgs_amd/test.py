@@ -222,6 +222,22 @@ def resolve_poses(id_module, sol, packed_host):
     return again["c2w"].cpu()
 
 
+def _sweep_cu_config():
+    """SIXDGS_SWEEP_CU_MASK: CUs taken away from the sweep's stream, as "<n>" (n CUs of XCD 7) or "<n>x8" (n CUs of every XCD); unset / 0: no mask.
+    -> (xcd_cus [8] | None, mask words | None)."""
+    from . import ops as _ops
+    v = os.environ.get("SIXDGS_SWEEP_CU_MASK", "").strip().lower()
+    if not v or v == "0":
+        return None, None
+    if v.endswith("x8"):
+        xc = [_ops.CUS_PER_XCD - int(v[:-2])] * _ops.N_XCD
+    else:
+        xc = [_ops.CUS_PER_XCD] * (_ops.N_XCD - 1) + [_ops.CUS_PER_XCD - int(v)]
+    if min(xc) < 1:
+        raise RuntimeError(f"6dgs_amd: SIXDGS_SWEEP_CU_MASK={v} leaves an XCD without CUs")
+    return xc, _ops.cu_mask_words(xc, os.environ.get("SIXDGS_CU_MASK_LAYOUT", "xcd-minor"))
+
+
 class PoseStream:
     """Batches of query images through `estimate_poses` as a PIPELINE: the reference's evaluation is exactly such a stream of views
     (pose_estimation/test.py:46-302), and poses/s over a test set is what the metric counts.
@@ -229,12 +245,16 @@ class PoseStream:
       handle = ps.submit(images, gt)      # enqueue everything of this batch; returns at once
       c2w, sol = ps.collect(handle)       # later: the batch's poses on the host
 
-    With one batch submitted before the previous one is collected, (a) the host never sits between the GPU's last kernel of batch N and its
-    first of batch N + 1 (round 4: every step ended in a device sync before the next image side was even enqueued), and (b) the image side of
-    batch N + 1 -- ~250 small kernels, ViT-S/14 + camera-up CNN -- runs on its OWN stream, so it fills the compute units the sweep of batch N
-    frees in its tail and overlaps batch N's small serial kernels (finish of U, selections, re-score, pose solve, D2H).  The scorer itself
-    stays in order on the caller's stream (one sweep holds every CU: its registers and LDS leave room for nothing else).
-    Poses are bit-identical to the unpipelined run: the same kernels on the same data in the same order per batch.
+    Three streams (round 6; round 5 had the first two):
+      image stream  ViT-S/14 -> tokens, then the camera-up CNN of batch N + 1 (two hipGraphs, ~250 small launches);
+      sweep stream  q_proj, sample pre-pass and the matrix-core sweep -- the caller's stream, or (SIXDGS_SWEEP_CU_MASK) a CU-masked stream of its own;
+      tail stream   everything BEHIND the sweep of batch N: merge of the token partials, U, thresholds, candidates, exact re-score, top-k, pose solve, the
+                    batch's one D2H -- ~25 launches that keep a handful of CUs busy for ~1.3 ms.  In round 5 they sat between sweep N and pre-pass N + 1.
+    The select path then alternates between TWO workspaces (the tail of N reads one while N + 1 sweeps into the other); scenes that leave no room for
+    the second one keep round 5's order (tail on the sweep's stream).  A persistent sweep holds every CU it may use, so without a CU mask the sweep of
+    N + 1 is held until the tail of N has retired (what overlaps is that tail and the pre-pass of N + 1); with a mask the tail and the image side have
+    CUs of their own WHILE a sweep runs and nothing waits.  Poses are bit-identical to the unpipelined run: the same kernels on the same data.
+    SIXDGS_POSE_STREAM_TAIL=0: round 5's two streams.
 
     Inputs of batch N must exist before submit(N - 1) was called, or be produced on `ps.image_stream` (uploads under
     `with torch.cuda.stream(ps.image_stream)`): the image stream does not wait for the caller's stream beyond that point."""
@@ -242,16 +262,27 @@ class PoseStream:
     def __init__(self, id_module, rays_ori, rays_dirs, rays_rgb, k: int = 100, workspace=None, images_in_flight=None):
         self.idm, self.rays, self.k = id_module, (rays_ori, rays_dirs, rays_rgb), k
         self.workspace, self.images_in_flight = workspace, images_in_flight
-        self.image_stream = torch.cuda.Stream(device=rays_ori.device)
-        self._fence = None            # recorded on the caller's stream at the START of the previous submit
+        dev = rays_ori.device
+        self.image_stream = torch.cuda.Stream(device=dev)
+        self._fence = None            # recorded on the sweep stream at the START of the previous submit
+        self.use_tail = os.environ.get("SIXDGS_POSE_STREAM_TAIL", "1") != "0"
+        self.tail_stream = torch.cuda.Stream(device=dev) if self.use_tail else None
+        self.xcd_cus, words = _sweep_cu_config() if self.use_tail else (None, None)
+        self.sweep_stream = ops.cu_masked_stream(dev, words) if words is not None else None
+        self._split_ok = None         # decided at the first submit: is there room for the second select workspace?
+        self._tail_done = [None, None]        # event behind the tail that last used select workspace 0 / 1
+        self._n = 0
 
     @torch.no_grad()
     def submit(self, images, gt_c2w=None, profile=None, tokens=None, up=None):
-        main = torch.cuda.current_stream()
+        caller = torch.cuda.current_stream()
+        main = self.sweep_stream if self.sweep_stream is not None else caller
         side = self.image_stream
+        if main is not caller and self._n == 0:
+            main.wait_stream(caller)             # the scene's key planes, weights and rays were produced on the caller's stream
         if tokens is None:
             if self._fence is None:
-                side.wait_stream(main)
+                side.wait_stream(caller)
             else:
                 side.wait_event(self._fence)
             fence = torch.cuda.Event()
@@ -279,23 +310,51 @@ class PoseStream:
                     ready.record(side)
                     up_ready = ready
             main.wait_event(ready)
-            for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))) + [up]:
-                t.record_stream(main)          # allocated on the image stream, read on the caller's
+            for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))):
+                t.record_stream(main)          # allocated on the image stream, read on the sweep's
         else:
             up_ready = None
-        idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
-                                                     images_in_flight=self.images_in_flight, profile=profile, defer_status=True)
-        if up_ready is not None:
-            main.wait_event(up_ready)
-        sol = _solve_batch(self.idm, idx, weights, scores, tokens, up, self.rays[0], self.rays[1], gt_c2w, True)
-        # the batch's ONE D2H, behind an event instead of a device sync: [c2w (16) | select status | solve status | t err | ang err | mean kept weight | kept]
-        full = torch.cat([sol["packed"], sol["status"].to(torch.float32)[:, None], sol["errors"].to(torch.float32),
-                          (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1))[:, None], sol["n_kept"].to(torch.float32)[:, None]], dim=1)
-        host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
-        host.copy_(full, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(main)
-        return {"sol": sol, "host": host, "done": done}
+            if main is not caller:
+                main.wait_stream(caller)       # injected tokens / camera-up vectors come from the caller's stream
+        b = len(tokens) if not torch.is_tensor(tokens) else tokens.shape[0]
+        if self._split_ok is None:
+            self._split_ok = bool(self.use_tail and self.idm.second_select_workspace_fits(b, self.rays[0].shape[0], self.rays[0].device, self.k))
+        slot = self._n & 1
+        self._n += 1
+        split = None
+        if self._split_ok:
+            if self._tail_done[slot] is not None:
+                main.wait_event(self._tail_done[slot])          # workspace `slot` is free again once the tail that read it last has retired
+            # without a CU mask the sweep waits for the PREVIOUS batch's tail: a persistent sweep leaves that tail no CU to finish on
+            split = ops.SelectSplit(self.tail_stream, wait_event=self._tail_done[slot ^ 1] if self.sweep_stream is None else None, xcd_cus=self.xcd_cus)
+        with torch.cuda.stream(main):
+            idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
+                                                         images_in_flight=self.images_in_flight, profile=profile, defer_status=True, split=split,
+                                                         ws_slot=slot)
+        tail = self.tail_stream if self._split_ok else main
+        if tail is not main:
+            tail.wait_stream(main)             # (the two-pass fallback of a whole batch leaves its results on the sweep's stream)
+            pend = getattr(self.idm, "pending_select", None)
+            for t in [idx, weights] + ([pend["status"], pend["q"], pend["n_tok"]] if pend is not None else []):
+                t.record_stream(tail)          # allocated on the sweep's stream, read by the tail
+        with torch.cuda.stream(tail):
+            if up_ready is not None:
+                tail.wait_event(up_ready)
+            if tail is not side and up is not None:
+                up.record_stream(tail)
+            if gt_c2w is not None and tail is not caller:
+                gt_c2w.record_stream(tail)
+            sol = _solve_batch(self.idm, idx, weights, scores, tokens, up, self.rays[0], self.rays[1], gt_c2w, True)
+            # the batch's ONE D2H, behind an event instead of a device sync: [c2w (16) | select status | solve status | t err | ang err | mean kept weight | kept]
+            full = torch.cat([sol["packed"], sol["status"].to(torch.float32)[:, None], sol["errors"].to(torch.float32),
+                              (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1))[:, None], sol["n_kept"].to(torch.float32)[:, None]], dim=1)
+            host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
+            host.copy_(full, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(tail)
+        if self._split_ok:
+            self._tail_done[slot] = done
+        return {"sol": sol, "host": host, "done": done, "keep": full}
 
     @torch.no_grad()
     def collect(self, handle):

@@ -106,6 +106,7 @@ def parse():
     ap.add_argument("--skip-reference-mode", action="store_true", help="skip the secondary reference-mode figure (1000-ellipsoid quadricell emission)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    ap.add_argument("--b8-steps", type=int, default=-1, help="headline: timed steps of the secondary 8-images-per-step figure (headline_b8); -1 = half of --steps, 0 = skip")
     ap.add_argument("--scenes", default="", help="cfg5-standin: comma-separated substrings of the scene names to run (default: all twelve)")
     ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
     ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
@@ -350,13 +351,14 @@ def main():
     # stream of batches (test.py:46-302), so batch N + 1 is SUBMITTED before batch N's poses are collected -- the host never sits between two batches
     # and the image side of N + 1 (own stream) overlaps the small serial kernels behind sweep N.  Every batch still ends with its poses on the host.
     pipelined = bool(use_select and not args.graph and not args.no_pipeline and not ray_sharded and not streamed)
-    ps = tp.PoseStream(idm, ori, dr, rgb, workspace=ws) if pipelined else None
+    ps_main = tp.PoseStream(idm, ori, dr, rgb, workspace=ws) if pipelined else None
     last_host, rank_s = [None], [0.0]
 
-    def timed(n_steps, p):
+    def timed(n_steps, p, ps=None, images=images, gts=gts, batch=args.batch):
         """exactly n_steps steps bracketed by barrier + synchronize; (max-over-ranks seconds, per-step seconds, last results).  Pipelined: per-step
         seconds are the intervals between the COMPLETIONS of consecutive batches (poses on the host); with several ranks the poses of all steps go
         to rank 0 in ONE fixed-size gather at the end (north_star: "a final gather") instead of one per step behind the next batch's sweep."""
+        ps = ps if ps is not None else ps_main
         torch.cuda.synchronize()
         dd.barrier()
         per, t_begin = [], time.perf_counter()
@@ -379,9 +381,9 @@ def main():
                 prev = cur
             host = local[-1]
             if dd.is_dist():
-                allp, _ = dd.gather_poses(torch.cat(local).to(dev), None, 0, counts=[args.batch * n_steps] * world)
+                allp, _ = dd.gather_poses(torch.cat(local).to(dev), None, 0, counts=[batch * n_steps] * world)
                 if allp is not None:
-                    host = allp.cpu().view(world, n_steps, args.batch, 4, 4)[:, -1].reshape(-1, 4, 4)
+                    host = allp.cpu().view(world, n_steps, batch, 4, 4)[:, -1].reshape(-1, 4, 4)
             last_host[0] = host
         torch.cuda.synchronize()
         rank_s[0] = time.perf_counter() - t_begin          # this rank's own time for its n_steps steps (before the closing barrier)
@@ -390,8 +392,8 @@ def main():
 
     for _ in range(args.warmup):
         step(None)
-        if ps is not None and use_select and ops.select_enabled():      # ... and through the pipelined path itself (its stream, its first graph replay there, its pinned buffers)
-            ps.collect(ps.submit(images, gts))
+        if ps_main is not None and use_select and ops.select_enabled():      # ... and through the pipelined path itself (its stream, its first graph replay there, its pinned buffers)
+            ps_main.collect(ps_main.submit(images, gts))
     elapsed, per_step, sol = timed(args.steps, None if args.graph else prof)
     per_rank_s = dd.all_floats(rank_s[0], dev)          # every rank's own time for the K steps: the line names the slowest rank
     if args.graph:        # HIP events cannot be read out of a captured graph: the kernel's duration comes from a few EAGER steps of the same batch
@@ -453,8 +455,12 @@ def main():
                          + "; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
             "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R_total, "images_per_gpu_per_step": args.batch,
             "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
-            "pipeline": ("2 batches in flight (6dgs_amd.test.PoseStream): batch N + 1 submitted before batch N's poses are collected, its image side on a second "
-                         "stream; scorer in order on one stream; one D2H per batch behind an event; --no-pipeline = one batch at a time" if pipelined
+            "pipeline": (("2 batches in flight (6dgs_amd.test.PoseStream): batch N + 1 submitted before batch N's poses are collected; image side on its own stream; "
+                          + ("the tail of a batch (U, candidates, re-score, top-k, pose solve, D2H) on a third stream beside the next batch's pre-pass"
+                             + (f" and sweep (sweep stream CU-masked: {ps_main.xcd_cus} CUs per XCD)" if ps_main.sweep_stream is not None else
+                                " (the next sweep waits for it: no CU mask)") + ", two select workspaces"
+                             if ps_main._split_ok else "scorer and its tail in order on one stream")
+                          + "; one D2H per batch behind an event; --no-pipeline = one batch at a time") if pipelined
                          else "none: one batch at a time, a device sync per step"),
             # select path: how the library cut this batch into sweep launches -- (256-token tiles, images) per launch, from the library's own planner with
             # the token counts of the last batch (csrc/sweep_plan.h: launches of 8 tiles, images packed into tiles by token count; SIXDGS_SWEEP_MAX_IMAGES)
@@ -487,6 +493,26 @@ def main():
         out["config"]["tokens_per_image"] = [int(tk[i].shape[0]) for i in range(len(tk))]
     if cand is not None:
         out["config"]["select_candidates_last_batch"] = cand
+    # ---- secondary figure: the same scene at 8 images per GPU and step -- BASELINE.md's batches are 64 / 128 views over 8 GPUs = 8 / 16 per
+    # GPU; a sweep launch of 8 tiles shares every key tile 8 ways instead of 4 and the per-batch tail is paid once per 8 poses.  Same path, same pipeline.
+    if args.config == "headline" and pipelined and args.batch != 8 and args.b8_steps != 0 and args.mode == "full":
+        cams8 = syn.make_cameras(8, 500 + rank, width=args.image_size, height=args.image_size)
+        images8 = [torch.from_numpy(c["image"]).to(dev) for c in cams8]
+        gts8 = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams8]).to(dev)
+        tp.prime_image_graph(idm, images8)
+        ps8 = tp.PoseStream(idm, ori, dr, rgb)
+        for _ in range(2):
+            ps8.collect(ps8.submit(images8, gts8))
+        n8 = max(2, args.steps // 2) if args.b8_steps < 0 else args.b8_steps
+        p8 = ops.KernelProfile()
+        e8, per8, _ = timed(n8, p8, ps=ps8, images=images8, gts=gts8, batch=8)
+        m8, f8, _, c8 = p8.collect()
+        out["headline_b8"] = {"value": round(world * 8 * n8 / e8, 4), "unit": "poses/s", "images_per_gpu_per_step": 8, "steps": n8, "ms_per_step": round(1e3 * e8 / n8, 3),
+                              "median_step_ms": round(1e3 * statistics.median(per8), 3), "sweep_avg_launch_ms": round(m8 / max(c8, 1), 4),
+                              "sweep_tflops": round(f8 / (m8 * 1e-3) / 1e12, 2) if m8 > 0 else None,
+                              "note": "the headline workload at 8 images per GPU and step (one sweep launch of 8 tiles), same pipeline; `value` above stays the 4-image figure of rounds 1-5"}
+        del ps8, images8, gts8
+        idm._select_ws = idm._select_ws_b = None
     if l24 is not None:
         out["two_pass_mode"] = l24
     if l32 is not None:

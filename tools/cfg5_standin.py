@@ -226,7 +226,8 @@ def run(args, torch, pkg, syn, dd, ops, tp, idm, dev, rank, world, peak_tflops):
                 "value_rel_err_select": float(np.abs(v1[0].cpu().numpy() - s[i1[0].cpu().numpy()]).max() / s.max()),
                 "pose_rel_err": float(np.abs(solp["c2w"][0].cpu().numpy() - p_ref["c2w"]).max() / scale),
                 # the metric's own error measures (error_computation.py:3-8) between the HIP pose and the ORACLE's pose of the same view
-                "rot_err_deg_vs_oracle": float(np.degrees(np.arccos(np.clip((np.trace(solp["c2w"][0, :3, :3].cpu().numpy().astype(np.float64) @ p_ref["c2w"][:3, :3].astype(np.float64).T) - 1.0) / 2.0, -1.0, 1.0)))),
+                # (rotation angle from the chord |R_h - R_o|_F = 2 sqrt(2) sin(theta / 2): acos of the trace has a floor of ~0.02 deg for fp32 matrices)
+                "rot_err_deg_vs_oracle": float(np.degrees(2.0 * np.arcsin(min(1.0, np.linalg.norm(solp["c2w"][0, :3, :3].cpu().numpy().astype(np.float64) - p_ref["c2w"][:3, :3].astype(np.float64)) / (2.0 * np.sqrt(2.0)))))),
                 "trans_err_vs_oracle": float(np.linalg.norm(solp["c2w"][0, :3, 3].cpu().numpy().astype(np.float64) - p_ref["c2w"][:3, 3].astype(np.float64))),
                 "oracle_s": {"ray_mlp": round(t_mlp, 2), "scorer_topk_pose": round(t_pose, 2)}}
             if cpu_sample is None:
