@@ -57,8 +57,6 @@ SIGNATURES = {
     "sixdgs_ray_keys_workspace_bytes": (sz, [i64, i64]),
     "sixdgs_ray_keys": (i32, [vp, vp, vp, i64, C.POINTER(ScorerWeights), vp, vp, vp, sz, vp]),
     "sixdgs_ray_keys_ex": (i32, [vp, vp, vp, i64, C.POINTER(ScorerWeights), vp, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile), i32]),
-    "sixdgs_key_planes_bytes": (sz, [i64]),
-    "sixdgs_split_planes": (i32, [vp, i64, i64, vp, vp]),
     "sixdgs_key_planes_f16_bytes": (sz, [i64]),
     "sixdgs_split_planes_f16": (i32, [vp, i64, i64, vp, vp, vp]),
     "sixdgs_score_pass1": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, sz, vp, C.POINTER(Profile), i32]),

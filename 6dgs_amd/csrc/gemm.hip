@@ -475,6 +475,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
   SDG_CHECK_ARG(ori && dir && rgb && ws && (feat || key || key_planes));
   const bool f16 = key_planes && (mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32 || mma_mode == SIXDGS_MMA_DEFAULT);
   SDG_CHECK_ARG(!f16 || key_inv_scale);
+  if (key_planes && !f16) return SIXDGS_E_UNSUPPORTED;      // key planes exist in one format: scaled fp16 (the three-plane bf16 format went with its scorer kernel, round 6)
   if (kChunkFloatsPerRay * sizeof(float) < (size_t)SIXDGS_D * sizeof(float) + dense_chain_bytes_per_ray()) return SIXDGS_E_WORKSPACE;
   const int64_t chunk_cap = (int64_t)(ws_bytes / (kChunkFloatsPerRay * sizeof(float))) - kChunkSlackRays;
   if (chunk_cap < 1) return SIXDGS_E_WORKSPACE;
@@ -554,7 +555,7 @@ int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int
         st = sixdgs_split_planes_f16(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, stream);
         if (!st && d_key_norm_max)      // (the fused path above takes the norms from the k_proj epilogue; here: one pass over the planes)
           st = sixdgs_key_planes_norm_max((char*)key_planes + (size_t)r0 * 1536, key_inv_scale + r0 / 128, m, d_key_norm_max, stream);
-      } else if (key_planes) st = sixdgs_split_planes(kdst, m, SIXDGS_D, (char*)key_planes + (size_t)r0 * 2304, stream);
+      }
       if (st) return st;
     }
   }

@@ -7,10 +7,10 @@
 //
 // The softmax runs over the RAY axis (rows = image tokens): its row statistics must be complete before any column sum can
 // be formed, so the [T, R] logits are written once to a caller-provided workspace and streamed back, instead of recomputing
-// the contraction in a second pass.  Three logits kernels, selected by SIXDGS_MMA_* (include/sixdgs.h):
-//   k_logits_f16x   (default)  scaled fp16 planes x 3 MFMA terms, 256 x 256 tiles, 24-bit (or fp32) blocked logits
-//   k_logits_v2     BF16X6 on pre-split bf16 planes, 128 x 128 tiles, fp32 token-major logits
-//   k_logits<MMA>   fp32 keys: fp32 MFMA chain (F32) or bf16 x 6 with the split done on the fly
+// the contraction in a second pass.  Two logits kernels, selected by the operands and SIXDGS_MMA_* (include/sixdgs.h):
+//   k_logits_f16x   (default; key PLANES)  scaled fp16 planes x 3 MFMA terms, 256 x 256 tiles, 24-bit (or fp32) blocked logits; the select sweep
+//   k_logits<MMA>   (fp32 KEYS: sixdgs_score_topk, the plain entry point on a [R,384] key matrix; scenes below 4 M rays keep one)  bf16 x 6 with the
+//                   split done on the fly, or -- SIXDGS_MMA_F32 -- the fp32 MFMA chain, which the parity tests use as the independent arithmetic
 // followed by k_merge_stats, k_score_reduce(_blocked, _blocked24) and the top-k kernels.  DESIGN.md 3a / 3b tell how the
 // default kernel got its shape and what bounds it.
 #include <stdlib.h>
@@ -110,338 +110,11 @@ __global__ void __launch_bounds__(256, 2) k_logits(LogitsArgs A) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// pass 1, v2: bf16x6 on PRE-SPLIT operand planes streamed by LDS-DMA.
-//
-// Operands: q planes [B][256][12 slabs][3 planes][32 k] bf16 and key planes [R][12][3][32] bf16 (2304 B per
-// row; written once by k_split_planes).  Per 32-k slab a workgroup needs 2 x 3 regions of 128 rows x 64 B.
-// Each region is filled by 8 global_load_lds_dwordx4 wave-instructions (1 KiB each, LDS image lane-linear);
-// the per-lane SOURCE address carries an XOR swizzle (16-byte chunk c of row r lands at position
-// c ^ ((r>>2)&3)) so that the ds_read_b128 fragment reads are bank-conflict free without padding.
-// 3-stage ring (144 KiB, one workgroup per CU): the DMA of slab s+2 is issued right after the barrier of
-// slab s, waits are counted (vmcnt(12) keeps the next slab in flight), fragment reads are inline asm so the
-// compiler does not drain the DMA queue in front of them.  No register staging, no split, no ds_write in the
-// main loop: per slab and wave 12 DMA + 24 ds_read_b128 + 48 MFMA (1536 matrix-pipe cycles).
-// Epilogue: logits = acc * (1/sqrt 384) (one rounding instead of torch's true division: <= 1 ulp of a logit,
-// two orders below the accumulation error), row statistics by a 31-exchange transpose-reduce per statistic
-// instead of 32 x 5 shuffles.
-// ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-constexpr int kRegion = 8192;            // 128 rows x 64 B
-constexpr int kStageV2 = 6 * kRegion;    // A planes 0..2, B planes 0..2
-constexpr int kRingV2 = 3 * kStageV2;
-constexpr int kRowBytes = 12 * 3 * 64;   // 2304 B of planes per operand row
+constexpr int kRowBytes = 12 * 3 * 64;   // 2304 B: the q-plane slot of the two-pass workspace keeps the size round 1's bf16 x 6 plane scorer gave it (that kernel and its
+                                         // three-plane key format were removed in round 6: nothing launched them outside their own tests; workspace sizes stay what callers know)
 constexpr float kInvSqrtD = 0.05103103630798288f;   // (float)(1/sqrt(384))
-
-struct LogitsV2Args {
-  const char* qp;        // [B][256][2304 B]
-  const int* n_tok;
-  const char* kp;        // [R][2304 B]
-  float* logits;
-  float* partial;
-  int64_t r, ldl;
-  int tiles_per_group, n_tiles, n_groups, b0;
-};
-
-__device__ __forceinline__ bf16x8 lds_read_frag(unsigned addr) {
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-
-// reduce 32 per-lane values across the 32 lanes of each half-wave; afterwards lane (l & 31) == j holds the
-// reduction of slot j.  31 exchanges instead of 32 x 5.
-template <bool IS_MAX>
-__device__ __forceinline__ float transpose_reduce32(float (&v)[32], int lane) {
-#pragma unroll
-  for (int o = 16, n = 16; o >= 1; o >>= 1, n >>= 1) {
-    // lanes with bit `o` set keep the upper half of the remaining slots and send the lower half.  The select is
-    // written as a bit-field insert on the raw bits: a `cond ? v[j+n] : v[j]` form is rewritten by LLVM into a
-    // dynamically indexed vector extract, which lowers to a 32-way compare/select chain per access.
-    const unsigned m = (lane & o) ? 0xffffffffu : 0u;
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      const unsigned lo = __float_as_uint(v[j]), hi = __float_as_uint(v[j + n]);
-      const float keep = __uint_as_float((hi & m) | (lo & ~m));
-      const float send = __uint_as_float((lo & m) | (hi & ~m));
-      const float recv = __shfl_xor(send, o, 64);
-      v[j] = IS_MAX ? fmaxf(keep, recv) : keep + recv;
-    }
-  }
-  return v[0];
-}
-// slot j (0..31) of a lane <-> accumulator (tm = j >> 4, r = j & 15); the butterfly above leaves slot
-// bit4 = lane bit4, ..., bit0 = lane bit0, i.e. lane k owns slot k.
-
-// ABL (debug ablation bits, 0 in production): 1 = Q-plane DMA only for the first tile, 2 = no epilogue,
-// 4 = no MFMA, 8 = key DMA only for the first tile.  Results are wrong for ABL != 0; timing only.
-template <int ABL>
-__global__ void __launch_bounds__(256, 1) k_logits_v2(LogitsV2Args A) {
-  __shared__ __attribute__((aligned(1024))) char lds[kRingV2 + 2 * 128 * 8 + 4 * 64 * 4];
-  float(*part)[128][2] = reinterpret_cast<float(*)[128][2]>(lds + kRingV2);
-  float* rowmax = reinterpret_cast<float*>(lds + kRingV2 + 2 * 128 * 8);   // [4 waves][64 rows]
-  const int bl = blockIdx.y;
-  const int b = A.b0 + bl;
-  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
-  const int grp = (int)(w >> 1), m_tile = (int)(w & 1u);
-  const int M = A.n_tok[b];
-  const int row0 = m_tile * 128;
-  float* pout = A.partial + (((int64_t)bl * A.n_groups + grp) * kT + row0) * 2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  float m_run = -INFINITY, s_run = 0.f;
-  const int t_begin = grp * A.tiles_per_group;
-  const int t_end = min(t_begin + A.tiles_per_group, A.n_tiles);
-  if (row0 < M && t_begin < t_end) {
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
-    // ---- DMA pieces.  Piece i of this wave is 1-KiB block n = 4 i + wave of the stage image, so its region
-    //      (i >> 1: A planes 0..2 for i < 6, B planes 0..2 for i >= 6) is a compile-time property and only the
-    //      position inside the region depends on the wave.  Per lane: a 32-bit byte offset against a
-    //      wave-uniform operand base; the slab stride (192 B) is folded into the address by the unrolled loop.
-    unsigned offA[6], offB[6];
-    int rowB[6];   // per-lane row of key piece i inside the 128-ray tile
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int sub = 4 * (i & 1) + wave;
-      const int chunk = sub * 64 + lane;
-      const int row = chunk >> 2, pos = chunk & 3;
-      const int c = pos ^ ((row >> 2) & 3);
-      const unsigned inrow = (unsigned)(((i >> 1) % 3) * 64 + c * 16);
-      if (i < 6) {
-        const int rr = min(row0 + row, M - 1);        // rows beyond the image's tokens re-read the last valid row
-        offA[i] = (unsigned)rr * kRowBytes + inrow;
-      } else {
-        rowB[i - 6] = row;
-        offB[i - 6] = inrow;
-      }
-    }
-    const char* qbase = A.qp + (int64_t)b * kT * kRowBytes;
-    // issue the 12 pieces of slab `s` of the tile whose key rows start at `kbase` into ring stage `stage`
-    // (both compile-time after unrolling).  `lim` = last valid key row of that tile relative to kbase: rows beyond
-    // the last ray re-read it (their columns are masked in the epilogue).
-    bool first_tile = true;
-    // one DMA piece (i = 0..5: key pieces from HBM first, i = 6..11: q-plane pieces, L2 hits) of slab `s` of the tile
-    // whose key rows start at `kbase` into ring stage `stage`; s, stage, i are compile-time after unrolling.  `lim` =
-    // last valid key row of that tile relative to kbase: rows beyond the last ray re-read it (masked in the epilogue).
-    auto issue_piece = [&](const char* kbase, int lim, const int s, const int stage, const int i) {
-      char* sbase = lds + stage * kStageV2 + wave * 1024;
-      if (i < 6) {
-        const unsigned ob = (unsigned)min(rowB[i], lim) * kRowBytes + offB[i] + (unsigned)(s * 192);
-        if (!(ABL & 8) || first_tile)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob), (lds_ptr_t)(sbase + (3 + (i >> 1)) * kRegion + (i & 1) * 4096), 16, 0, 0);
-      } else {
-        const int k = i - 6;
-        if (!(ABL & 1) || first_tile)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offA[k] + (unsigned)(s * 192))),
-                                           (lds_ptr_t)(sbase + (k >> 1) * kRegion + (k & 1) * 4096), 16, 0, 0);
-      }
-    };
-    auto issue = [&](const char* kbase, int lim, const int s, const int stage) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) issue_piece(kbase, lim, s, stage, i);
-    };
-    auto tile_lim = [&](int tile) {
-      const int64_t left = A.r - (int64_t)tile * kBN - 1;      // >= 0
-      return left < 127 ? (int)left : 127;
-    };
-    // ---- fragment read addresses (relative to the stage base) -----------------------------------------------
-    unsigned fa[2][2], fb[2][2];   // [row block t][k-step ks]
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int c = 2 * ks + (lane >> 5);
-        const int ra = wm * 64 + t * 32 + (lane & 31), rb = wn * 64 + t * 32 + (lane & 31);
-        fa[t][ks] = lds0 + ra * 64 + ((c ^ ((ra >> 2) & 3)) << 4);
-        fb[t][ks] = lds0 + 3 * kRegion + rb * 64 + ((c ^ ((rb >> 2) & 3)) << 4);
-      }
-
-    float* lg = A.logits + (int64_t)bl * kT * A.ldl;
-    // lane part of a logit address: (4 (lane>>5)) rows + wn*64 + (lane & 31) columns, as a 32-bit element offset
-    const unsigned lane_elem = (unsigned)(4 * (lane >> 5)) * (unsigned)A.ldl + (unsigned)(wn * 64 + (lane & 31));
-    const char* kcur = A.kp + (int64_t)t_begin * kBN * kRowBytes;
-    int lim_cur = tile_lim(t_begin);
-    // 12 slabs per tile = 0 mod 3: slab s of every tile lives in ring stage s % 3.
-    // Schedule (fragment registers double-buffered, so the LDS latency of the next k-step hides under the MFMAs of
-    // the current one):   B(k) = { wait slab k landed; barrier; issue DMA of slab k+2 }
-    //   B(0); F0 <- (0, ks0); wait
-    //   for sl: F1 <- (sl, ks1); MFMA(F0); wait; B(sl+1); F0 <- (sl+1, ks0); MFMA(F1); wait
-    // B(12) / F0(12) are B(0) / F0(0) of the next tile.  When a wave reaches B(sl+1) all of its reads of slab sl have
-    // completed (the wait before it), so after the barrier the stage of slab sl may be refilled with slab sl+3.
-    auto B = [&](const char* kb, int lim, const int sl_local, const bool last_wait) {
-      // sl_local: slab index within ITS tile (0..11) whose arrival is awaited; issues slab sl_local + 2 of the same
-      // tile, or slabs 0/1 of the following tile when sl_local is 10/11.
-      if (last_wait || (ABL & 9)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      (void)kb; (void)lim;
-    };
-    bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
-    auto read_frags = [&](bf16x8 (&fa_)[2][3], bf16x8 (&fb_)[2][3], const int stage, const int ks) {
-      const unsigned st = (unsigned)(stage * kStageV2);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          fa_[t][p] = lds_read_frag(fa[t][ks] + st + p * kRegion);
-          fb_[t][p] = lds_read_frag(fb[t][ks] + st + p * kRegion);
-        }
-    };
-    auto wait_lds = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    issue(kcur, lim_cur, 0, 0);
-    issue(kcur, lim_cur, 1, 1);
-    // B(0) of the first tile
-    B(kcur, lim_cur, 0, false);
-    issue(kcur, lim_cur, 2, 2);
-    read_frags(f0a, f0b, 0, 0);
-    wait_lds();
-    for (int tile = t_begin; tile < t_end; ++tile) {
-      const int64_t col0 = (int64_t)tile * kBN;
-      const bool has_next = tile + 1 < t_end;
-      const char* knext = kcur + (int64_t)kBN * kRowBytes;
-      const int lim_next = has_next ? tile_lim(tile + 1) : 0;
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-      // 24 MFMAs on fragment set (xa, xb) with up to 24 "side" instructions interleaved one per MFMA slot: the 12
-      // fragment reads of the NEXT k-step and, optionally, the 12 DMA pieces of a later slab.  Issuing those as bursts
-      // in front of the MFMA block stalls the in-order wave on the LDS / TA queues while the matrix pipe idles.
-      auto mfma_step = [&](bf16x8 (&xa)[2][3], bf16x8 (&xb)[2][3], bf16x8 (&na)[2][3], bf16x8 (&nb)[2][3], const bool do_read,
-                           const int rstage, const int rks, const bool do_dma, const char* dkb, const int dlim, const int ds,
-                           const int dstage) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-        const unsigned st = (unsigned)(rstage * kStageV2);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-#pragma unroll
-          for (int z = 0; z < 4; ++z) {
-            const int slot = q * 4 + z;        // 0..23
-            const int tm = z >> 1, tn = z & 1;
-            if (!(ABL & 4))
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[tm][PA[q]], xb[tn][PB[q]], acc[tm][tn], 0, 0, 0);
-            if (do_read && !(ABL & 16) && (slot & 1) == 0) {  // 12 reads on the even slots
-              const int ridx = slot >> 1;      // 0..11: (operand, t, p)
-              const int op = ridx / 6, t = (ridx % 6) / 3, pp = ridx % 3;
-              if (op == 0) na[t][pp] = lds_read_frag(fa[t][rks] + st + pp * kRegion);
-              else nb[t][pp] = lds_read_frag(fb[t][rks] + st + pp * kRegion);
-            }
-            if (do_dma && (slot & 1) == 1) issue_piece(dkb, dlim, ds, dstage, slot >> 1);   // 12 pieces on the odd slots
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (ABL & 4) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p2 = 0; p2 < 3; ++p2) asm volatile("" ::"v"(xa[t][p2]), "v"(xb[t][p2]));
-        }
-      };
-
-      for (int s0 = 0; s0 < 12; s0 += 3) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {     // slab sl = s0 + u sits in ring stage u
-          const int sl = s0 + u;
-          // k-step 0 of slab sl; the reads of its k-step 1 ride along
-          mfma_step(f0a, f0b, f1a, f1b, true, u, 1, false, nullptr, 0, 0, 0);
-          wait_lds();
-          // B(sl + 1): the next slab (of this tile, or slab 0 of the next one) has landed for everyone
-          const bool more = sl < 11 || has_next;
-          if (more) {
-            const bool lastw = (sl == 10) && !has_next;   // slab 11 of the final tile: nothing younger in flight
-            B(kcur, lim_cur, sl + 1, lastw);
-            if (sl >= 9) first_tile = false;
-          }
-          // k-step 1 of slab sl; riding along: reads of (sl+1, ks0) and the DMA of slab sl + 3 into this slab's stage
-          const bool dma_same = more && (sl + 3 < 12);
-          const bool dma_next = more && (sl + 3 >= 12) && has_next;
-          if (dma_same) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 3, 0, true, kcur, lim_cur, sl + 3, u);
-          else if (dma_next) mfma_step(f1a, f1b, f0a, f0b, true, (u + 1) % 3, 0, true, knext, lim_next, sl + 3 - 12, u);
-          else mfma_step(f1a, f1b, f0a, f0b, more, (u + 1) % 3, 0, false, nullptr, 0, 0, 0);
-          wait_lds();
-        }
-      }
-
-      if (ABL & 2) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-        kcur = knext;
-        lim_cur = lim_next;
-        continue;
-      }
-      // ---- epilogue: scale, store, per-row (max, sum exp) of this 128-ray tile ----------------------------------
-      // Stores are unconditional: the workspace has 256 rows x ldl (>= R, multiple of 128) columns per image, so
-      // rows >= M and columns >= R land in padding that nobody reads.
-      const bool v0 = col0 + acc_col(wn, 0, lane) < A.r, v1 = col0 + acc_col(wn, 1, lane) < A.r;
-      float mx[32];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // wave-uniform part of the address: row row0 + wm*64 + tm*32 + (r&3) + 8 (r>>2), column col0 (+32 for tn = 1)
-          float* rowp = lg + (int64_t)(row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2)) * A.ldl + col0;
-          const float l0 = acc[tm][0][r] * kInvSqrtD, l1 = acc[tm][1][r] * kInvSqrtD;
-          acc[tm][0][r] = l0;
-          acc[tm][1][r] = l1;
-          rowp[lane_elem] = l0;
-          rowp[lane_elem + 32u] = l1;
-          mx[tm * 16 + r] = fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY);
-        }
-      const float my_max = transpose_reduce32<true>(mx, lane);      // lane k: max of slot k over this wave's 64 columns
-      // broadcast the 32 row maxima of this half-wave back to all of its lanes through LDS
-      float* rmx = rowmax + wave * 64 + (lane >> 5) * 32;
-      rmx[lane & 31] = my_max;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float sm[32];
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const float m = rmx[j];
-        const int tm = j >> 4, r = j & 15;
-        const float e0 = v0 ? __expf(acc[tm][0][r] - m) : 0.f, e1 = v1 ? __expf(acc[tm][1][r] - m) : 0.f;
-        sm[j] = (m > -INFINITY) ? e0 + e1 : 0.f;
-      }
-      const float my_sum = transpose_reduce32<false>(sm, lane);
-      {
-        const int j = lane & 31;
-        const int lr = acc_row(wm, j >> 4, j & 15, lane);
-        part[wn][lr][0] = my_max;
-        part[wn][lr][1] = my_sum;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tid < 128) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float mt = part[h][tid][0], st2 = part[h][tid][1];
-          if (mt > -INFINITY) {
-            const float mn = fmaxf(m_run, mt);
-            s_run = s_run * __expf(m_run - mn) + st2 * __expf(mt - mn);
-            m_run = mn;
-          }
-        }
-      }
-      // `part` is rewritten only after the 12 slab barriers of the next tile
-      kcur = knext;
-      lim_cur = lim_next;
-    }
-  }
-  if (tid < 128) {
-    pout[2 * tid] = m_run;
-    pout[2 * tid + 1] = s_run;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // pass 1, fp16x3 variant (SIXDGS_MMA_F16X3): TWO scaled fp16 planes per operand, THREE cross terms.
@@ -1095,16 +768,6 @@ __global__ void __launch_bounds__(256) k_split_tiles_f16(const float* __restrict
   }
 }
 
-// fp32 rows [rows][384] (row stride ld) -> bf16 planes [rows][12][3][32]; 8 consecutive k per thread
-__global__ void __launch_bounds__(256) k_split_planes(const float* __restrict__ src, int64_t rows, int64_t ld, char* __restrict__ dst) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * 48) return;
-  const int64_t row = i / 48;
-  const int k8 = (int)(i - row * 48);
-  const float4 lo = *reinterpret_cast<const float4*>(src + row * ld + k8 * 8);
-  const float4 hi = *reinterpret_cast<const float4*>(src + row * ld + k8 * 8 + 4);
-  split_store8(lo, hi, dst + row * kRowBytes + (k8 >> 2) * 192 + (k8 & 3) * 16);
-}
 
 // merge the per-group partial statistics: stats[b][t] = (max, sumexp).  Four threads per token take every fourth group
 // (independent load chains), then one thread folds the four partials in a fixed order.
@@ -2115,7 +1778,6 @@ size_t sixdgs_score_topk_workspace_bytes_ex(int64_t r, int batch, int topk, int 
   return p.topk_bytes + (size_t)batch * p.per_image();
 }
 
-size_t sixdgs_key_planes_bytes(int64_t r) { return (size_t)(r > 0 ? r : 0) * kRowBytes; }
 
 size_t sixdgs_key_planes_f16_bytes(int64_t r) { return (size_t)(r > 0 ? r : 0) * kRowF; }
 
@@ -2129,15 +1791,6 @@ int sixdgs_split_planes_f16(const float* src, int64_t rows, int64_t ld, void* pl
   return 0;
 }
 
-int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream) {
-  SDG_CHECK_ARG(rows >= 0 && ld >= SIXDGS_D && (ld % 4) == 0);
-  if (rows == 0) return 0;
-  SDG_CHECK_ARG(src && planes && ((uintptr_t)src % 16) == 0 && ((uintptr_t)planes % 16) == 0);
-  hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv(rows * 48, 256)), dim3(256), 0, sdg_stream(stream), src, rows, ld,
-                     (char*)planes);
-  SDG_LAUNCH_OK();
-  return 0;
-}
 
 }  // extern "C"
 
@@ -2153,9 +1806,11 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
   const bool f16_mode = mma_mode == SIXDGS_MMA_F16X3 || mma_mode == SIXDGS_MMA_F16X3_L32 || mma_mode == SIXDGS_MMA_DEFAULT;
   const bool use_f16 = (phase == 2 ? planes : key_planes != nullptr) && f16_mode;
   SDG_CHECK_ARG(phase == 2 || !use_f16 || d_key_scale != nullptr);
-  const bool use_v2 = (phase == 2 ? planes : key_planes != nullptr) && mma_mode != SIXDGS_MMA_F32;
+  // key planes are an operand of the fp16 x 3 kernels only.  (Round 1's bf16 x 6 plane scorer was removed in round 6: nothing outside its own tests
+  // launched it.  SIXDGS_MMA_BF16X6 / _F32 score on fp32 keys -- k_logits<MMA> below -- and need `key`.)
+  if ((phase == 2 ? planes : key_planes != nullptr) && !f16_mode && !(phase != 2 && key)) return SIXDGS_E_UNSUPPORTED;
   const bool logits24 = mma_mode != SIXDGS_MMA_F16X3_L32;         // 24-bit fixed-point logits between the passes (fp16x3 path)
-  SDG_CHECK_ARG(d_n_tok && ws && (phase == 2 || (q && (key || use_v2 || r == 0))) && (phase == 1 || (idx && val)) &&
+  SDG_CHECK_ARG(d_n_tok && ws && (phase == 2 || (q && (key || use_f16 || r == 0))) && (phase == 1 || (idx && val)) &&
                 (phase == 0 || row_stats));
   SDG_CHECK_ARG(((uintptr_t)key_planes % 16) == 0);
   SDG_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)key % 16) == 0 && ((uintptr_t)ws % 256) == 0);
@@ -2193,7 +1848,7 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
         // references) or 4 bytes per logit
         SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r,
                               use_f16 ? (double)r * (kRowF + tok * (logits24 ? 3.0 + 8.0 / 128.0 : 4.0))
-                                      : (double)r * (nb * (use_v2 ? 2304.0 : SIXDGS_D * 4.0) + tok * 4.0));
+                                      : (double)r * (nb * (SIXDGS_D * 4.0) + tok * 4.0));
         if (use_f16) {
           // scaled fp16 planes of q (one power-of-two scale per 128-token half), then the fp16x3 kernel
           float* qinv = (float*)(qplanes + (size_t)bg * (p.per_image_qplanes - 256));
@@ -2226,33 +1881,6 @@ int score_impl(int phase, bool planes, const float* q, const int32_t* d_n_tok, c
           }
 #endif
           hipLaunchKernelGGL(kern, dim3((unsigned)(n_groups_used * nb)), dim3(512), 0, s, V);
-        } else if (use_v2) {
-          // q planes of this image group (590 KB per image, L2 resident), then the DMA-fed bf16x6 kernel
-          hipLaunchKernelGGL(k_split_planes, dim3((unsigned)sdg_cdiv((int64_t)nb * kT * 48, 256)), dim3(256), 0, s,
-                             q + (int64_t)b0 * kT * SIXDGS_D, (int64_t)nb * kT, (int64_t)SIXDGS_D, qplanes);
-          LogitsV2Args V = {qplanes, d_n_tok, (const char*)key_planes, logits, partial, r, A.ldl, p.tiles_per_group, p.n_tiles,
-                            p.n_groups, b0};
-          V.qp = qplanes - (int64_t)b0 * kT * kRowBytes;   // the kernel indexes planes by absolute image number
-          const dim3 gg((unsigned)(p.n_groups * 2), (unsigned)nb);
-#ifdef SIXDGS_ABLATION   // timing experiments only (tools/ablate_logits.py builds a private copy of the library with it)
-          const char* ab = getenv("SIXDGS_DEBUG_ABLATE");
-          const int abl = ab ? atoi(ab) : 0;
-          switch (abl) {
-            case 0: hipLaunchKernelGGL(k_logits_v2<0>, gg, dim3(256), 0, s, V); break;
-            case 1: hipLaunchKernelGGL(k_logits_v2<1>, gg, dim3(256), 0, s, V); break;
-            case 2: hipLaunchKernelGGL(k_logits_v2<2>, gg, dim3(256), 0, s, V); break;
-            case 4: hipLaunchKernelGGL(k_logits_v2<4>, gg, dim3(256), 0, s, V); break;
-            case 6: hipLaunchKernelGGL(k_logits_v2<6>, gg, dim3(256), 0, s, V); break;
-            case 8: hipLaunchKernelGGL(k_logits_v2<8>, gg, dim3(256), 0, s, V); break;
-            case 9: hipLaunchKernelGGL(k_logits_v2<9>, gg, dim3(256), 0, s, V); break;
-            case 11: hipLaunchKernelGGL(k_logits_v2<11>, gg, dim3(256), 0, s, V); break;
-            case 18: hipLaunchKernelGGL(k_logits_v2<18>, gg, dim3(256), 0, s, V); break;
-            case 27: hipLaunchKernelGGL(k_logits_v2<27>, gg, dim3(256), 0, s, V); break;
-            default: return SIXDGS_E_BADARG;
-          }
-#else
-          hipLaunchKernelGGL(k_logits_v2<0>, gg, dim3(256), 0, s, V);
-#endif
         } else if (mma_mode == SIXDGS_MMA_F32) {
           hipLaunchKernelGGL(k_logits<kMmaF32>, dim3((unsigned)(p.n_groups * 2), (unsigned)nb), dim3(256), 0, s, A);
         } else {

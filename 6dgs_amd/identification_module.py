@@ -111,14 +111,15 @@ class IdentificationModule(torch.nn.Module):
             self._key_cache = None
         return self._packed
 
-    KEEP_FP32_KEYS_BELOW = 4_000_000   # rays; above, only the bf16 planes are cached (2304 B/ray vs 1536 + 2304)
+    KEEP_FP32_KEYS_BELOW = 4_000_000   # rays; above, only the scaled fp16 planes are cached (1536 B/ray instead of 1536 + 1536)
 
     def _ensure_keys(self, rays_ori, rays_dir, rays_rgb, profile=None, sample_min_rays: Optional[int] = None):
         w = self.packed_weights(rays_ori.device)
         # Identity of the cache entry: the three ray tensor OBJECTS (held strongly, so the allocator cannot hand their
         # addresses to a new ray set while the entry lives), their in-place versions, the weights and the MMA mode.
         mode = ops.effective_mma_mode()
-        fmt = "f32" if mode == ops.MMA_F32 else ("f16-planes" if mode in ops.F16_MODES else "bf16-planes")   # F16X3 / F16X3_L32 share planes
+        # F16X3 / F16X3_L32 share planes; MMA_F32 / MMA_BF16X6 score on fp32 keys (k_logits<MMA>), computed by the dense layers of that mode
+        fmt = "f16-planes" if mode in ops.F16_MODES else f"f32-keys-mma{mode}"
         smin = ops.SELECT_MIN_RAYS if sample_min_rays is None else int(sample_min_rays)     # scenes from this size get the select path's ray sample
         ident = (rays_ori.shape[0], rays_ori._version, rays_dir._version, rays_rgb._version, self._packed_key, fmt, rays_ori.shape[0] >= smin)
         held = self._key_cache_rays
@@ -131,20 +132,18 @@ class IdentificationModule(torch.nn.Module):
                 self._select_ws = self._select_ws_b = self._stream_sample = None
                 ops.get_arena().reset(self)
             r = rays_ori.shape[0]
-            planes_mode = mode != ops.MMA_F32
+            planes_mode = mode in ops.F16_MODES
             keep_fp32 = (not planes_mode) or r <= self.KEEP_FP32_KEYS_BELOW
             scale = None
-            norm = torch.zeros(1, device=rays_ori.device) if (planes_mode and mode in ops.F16_MODES) else None
+            norm = torch.zeros(1, device=rays_ori.device) if planes_mode else None
             if planes_mode:
                 # (norm: max |k_r| of the scene -- the select path's slack is derived from it, sixdgs.h: sixdgs_score_select)
-                _, key, planes = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True, norm_out=norm)
-                if mode in ops.F16_MODES:
-                    planes, scale = planes
+                _, key, (planes, scale) = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, want_key=keep_fp32, profile=profile, want_planes=True, norm_out=norm)
             else:
                 _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, w, profile=profile)
                 planes = None
             sample = None
-            if planes_mode and mode in ops.F16_MODES and r >= smin:
+            if planes_mode and r >= smin:
                 # the ray sample of the select path (ops.score_select): one ray in 16 through the same ray MLP (+6 % set-up work,
                 # +96 B per ray); its planes carry their own tile scales
                 si = ops.select_sample_indices(r, rays_ori.device)
@@ -156,7 +155,7 @@ class IdentificationModule(torch.nn.Module):
 
     def ray_keys(self, rays_ori, rays_dir, rays_rgb, profile=None) -> torch.Tensor:
         """K[R,384] = k_proj(RayPreprocessor(rays)) -- computed once per (ray tensors, weights) and cached, as fp32
-        and/or as the bf16 planes the fast scorer kernel streams."""
+        and/or as the scaled fp16 planes the fast scorer kernels stream."""
         c = self._ensure_keys(rays_ori, rays_dir, rays_rgb, profile)
         if c["key"] is None:   # large scene: fp32 copy on request only
             _, key = ops.ray_keys(rays_ori, rays_dir, rays_rgb, self.packed_weights(rays_ori.device))
@@ -386,7 +385,7 @@ class IdentificationModule(torch.nn.Module):
         b, r, k = q.shape[0], rays_ori.shape[0], rays_to_output
         chunk = max(256, (min(chunk_rays, max(r, 1)) + 255) // 256 * 256)       # whole 256-ray tiles (and fp16 scale tiles)
         mode = ops.effective_mma_mode()
-        f16, planes_mode = mode in ops.F16_MODES, mode != ops.MMA_F32
+        f16 = planes_mode = mode in ops.F16_MODES
         self.last_scoring_path = "streamed two-pass"
         if (f16 and use_select and not return_stats and ops.select_enabled() and r >= ops.SELECT_MIN_RAYS and k <= ops.SELECT_MAX_CANDIDATES
                 and not torch.cuda.is_current_stream_capturing()):
@@ -438,7 +437,7 @@ class IdentificationModule(torch.nn.Module):
         with ops.arena_scope():
             ws = ops.big_empty(ops.score_topk_workspace_bytes(min(chunk, r), b, k, planes=planes_mode), torch.uint8, dev)
             n_c = min(chunk, r)
-            per_ray = 1536 if f16 else (2304 if planes_mode else 4 * ops.D)
+            per_ray = 1536 if f16 else 4 * ops.D
             if key_cache_bytes is None:
                 # 70 % of what is free once the transient needs of ONE chunk are set aside: its key planes (they exist while the chunk is
                 # scored, kept or not) and the ray-MLP workspace of sixdgs_ray_keys_ex.  "Free" is the arena's room when the planes come from it.
@@ -455,8 +454,7 @@ class IdentificationModule(torch.nn.Module):
                 if not planes_mode:
                     _, key = ops.ray_keys(o, d, c, w)
                     return (key, None, None)
-                _, _, planes = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
-                planes, scale = planes if f16 else (planes, None)
+                _, _, (planes, scale) = ops.ray_keys(o, d, c, w, want_key=False, want_planes=True)
                 return (None, planes, scale)
 
             def chunk_pass1(r0, may_keep):

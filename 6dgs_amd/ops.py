@@ -365,16 +365,6 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
 
 
 @_on_device
-def split_planes(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [rows,384] -> bf16 planes as uint8 [rows, 2304] ([12 slabs][3 planes][32 k] per row)."""
-    x = _f32(x)
-    _need_gpu(x)
-    out = torch.empty(x.shape[0], 2304, dtype=torch.uint8, device=x.device)
-    check(_lib.load().sixdgs_split_planes(_p(x), x.shape[0], x.stride(0), _p(out), _stream()), "split_planes")
-    return out
-
-
-@_on_device
 def split_planes_f16(x: torch.Tensor):
     """fp32 [rows,384] -> (scaled fp16 planes as uint8 [rows,1536], reciprocal power-of-two scale of every 128-row tile)."""
     x = _f32(x)
@@ -497,8 +487,8 @@ def ray_keys_workspace_bytes(r: int, max_chunk: int = RAY_KEYS_CHUNK) -> int:
 def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want_key: bool = True, max_chunk: int = RAY_KEYS_CHUNK,
              workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, want_planes: bool = False,
              norm_out: Optional[torch.Tensor] = None):
-    """-> (feat | None, key | None)  or, with want_planes, (feat | None, key | None, planes) where planes is uint8 [R,2304]
-    (bf16 planes) or, in MMA_F16X3 mode, the pair (uint8 [R,1536] scaled fp16 planes, inv_scale [ceil(R/128)]).
+    """-> (feat | None, key | None)  or, with want_planes (F16X3 modes only), (feat | None, key | None, (uint8 [R,1536] scaled fp16 planes,
+    inv_scale [ceil(R/128)])).
     norm_out (device scalar [1], scaled fp16 planes only): updated to max(norm_out, max_r |key row|) -- see key_norm_max."""
     ori, dr, rgb = _f32(ori), _f32(dr), _f32(rgb)
     _need_gpu(ori, dr, rgb)
@@ -509,7 +499,9 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
     key = torch.empty(r, D, device=dev) if want_key else None
     mode = effective_mma_mode()
     f16 = want_planes and mode in F16_MODES
-    planes = big_empty((r, 1536 if f16 else 2304), torch.uint8, dev) if want_planes else None
+    if want_planes and not f16:
+        raise RuntimeError("6dgs_amd: key planes exist in the fp16 x 3 modes only (MMA_F32 / MMA_BF16X6 score on fp32 keys)")
+    planes = big_empty((r, 1536), torch.uint8, dev) if want_planes else None
     inv = torch.empty((r + 127) // 128, device=dev) if f16 else None
     nbytes = lib.sixdgs_ray_keys_workspace_bytes(r, int(max_chunk))
     if workspace is None or workspace.numel() < nbytes:
@@ -527,7 +519,7 @@ def ray_keys(ori, dr, rgb, weights: PackedWeights, want_feat: bool = False, want
         check(lib.sixdgs_ray_keys_ex(_p(ori), _p(dr), _p(rgb), r, weights.ref, _p(feat), _p(key), _p(planes), _p(inv), _p(norm_out), _p(ws), ws.numel(),
                                      _stream(), profile.ref if profile is not None else None, mode), "ray_keys")
     if want_planes:
-        return feat, key, ((planes, inv) if f16 else planes)
+        return feat, key, (planes, inv)
     return feat, key
 
 
@@ -568,8 +560,8 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
                want_stats: bool = False, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
                profile: Optional["KernelProfile"] = None, n_tok_host=None, key_planes: Optional[torch.Tensor] = None,
                key_scale: Optional[torch.Tensor] = None):
-    """key: fp32 [R,384] and/or key_planes: uint8 [R,2304] bf16 planes (BF16X6) or [R,1536] scaled fp16 planes + key_scale
-    (F16X3); planes select the DMA-fed kernels unless the mode is MMA_F32."""
+    """key: fp32 [R,384] and/or key_planes: uint8 [R,1536] scaled fp16 planes + key_scale (the F16X3 modes: the DMA-fed kernels);
+    MMA_F32 / MMA_BF16X6 score on the fp32 keys."""
     q = _f32(q)
     key = _f32(key) if key is not None else None
     _need_gpu(q, key, n_tok, key_planes)
@@ -587,10 +579,13 @@ def score_topk(q: torch.Tensor, n_tok: torch.Tensor, key: Optional[torch.Tensor]
     if profile is not None and n_tok_host is not None:
         h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host])
     mode = effective_mma_mode()
-    if key_planes is not None and mode != MMA_F32:
-        want = 1536 if mode in F16_MODES else 2304
-        if key_planes.shape[1] != want or (mode in F16_MODES and key_scale is None):
-            raise RuntimeError("6dgs_amd: key planes are not in the format of the active MMA mode")
+    if key_planes is not None and mode in F16_MODES:
+        if key_planes.shape[1] != 1536 or key_scale is None:
+            raise RuntimeError("6dgs_amd: key planes are not in the format of the active MMA mode (scaled fp16 planes [R,1536] + key_scale)")
+    elif key_planes is not None:
+        if key is None:
+            raise RuntimeError("6dgs_amd: MMA_F32 / MMA_BF16X6 score on fp32 keys: pass `key` (key planes are the operand of the fp16 x 3 kernels only)")
+        key_planes = key_scale = None
     check(lib.sixdgs_score_topk_ex(_p(q), _p(n_tok), h_n, b, _p(key), _p(key_planes), _p(key_scale), r, int(topk), _p(scores), _p(idx), _p(val), _p(stats),
                                    _p(workspace), workspace.numel(), _stream(), profile.ref if profile is not None else None,
                                    _mma_mode), "score_topk")

@@ -223,19 +223,20 @@ def resolve_poses(id_module, sol, packed_host):
 
 
 def _sweep_cu_config():
-    """SIXDGS_SWEEP_CU_MASK: CUs taken away from the sweep's stream, as "<n>" (n CUs of XCD 7) or "<n>x8" (n CUs of every XCD); unset / 0: no mask.
-    -> (xcd_cus [8] | None, mask words | None)."""
+    """SIXDGS_SWEEP_CU_MASK: CUs taken away from the sweep's stream and given to the image + tail streams, as "<n>" (n CUs of XCD 7) or "<n>x<m>" (n CUs
+    of each of the last m XCDs; "4x8" = 4 CUs of every XCD); unset / 0: no mask.  -> (xcd_cus [8] | None, sweep mask words | None, complement words | None)."""
     from . import ops as _ops
     v = os.environ.get("SIXDGS_SWEEP_CU_MASK", "").strip().lower()
     if not v or v == "0":
-        return None, None
-    if v.endswith("x8"):
-        xc = [_ops.CUS_PER_XCD - int(v[:-2])] * _ops.N_XCD
-    else:
-        xc = [_ops.CUS_PER_XCD] * (_ops.N_XCD - 1) + [_ops.CUS_PER_XCD - int(v)]
-    if min(xc) < 1:
-        raise RuntimeError(f"6dgs_amd: SIXDGS_SWEEP_CU_MASK={v} leaves an XCD without CUs")
-    return xc, _ops.cu_mask_words(xc, os.environ.get("SIXDGS_CU_MASK_LAYOUT", "xcd-minor"))
+        return None, None, None
+    n, m = (v.split("x") + ["1"])[:2]
+    n, m = int(n), int(m)
+    if not (1 <= m <= _ops.N_XCD and 1 <= n < _ops.CUS_PER_XCD):
+        raise RuntimeError(f"6dgs_amd: SIXDGS_SWEEP_CU_MASK={v}: need 1 <= CUs < {_ops.CUS_PER_XCD} of 1..{_ops.N_XCD} XCDs")
+    xc = [_ops.CUS_PER_XCD] * (_ops.N_XCD - m) + [_ops.CUS_PER_XCD - n] * m
+    layout = os.environ.get("SIXDGS_CU_MASK_LAYOUT", "xcd-minor")
+    words = _ops.cu_mask_words(xc, layout)
+    return xc, words, [(~w) & 0xFFFFFFFF for w in words]
 
 
 class PoseStream:
@@ -263,12 +264,17 @@ class PoseStream:
         self.idm, self.rays, self.k = id_module, (rays_ori, rays_dirs, rays_rgb), k
         self.workspace, self.images_in_flight = workspace, images_in_flight
         dev = rays_ori.device
-        self.image_stream = torch.cuda.Stream(device=dev)
         self._fence = None            # recorded on the sweep stream at the START of the previous submit
         self.use_tail = os.environ.get("SIXDGS_POSE_STREAM_TAIL", "1") != "0"
-        self.tail_stream = torch.cuda.Stream(device=dev) if self.use_tail else None
-        self.xcd_cus, words = _sweep_cu_config() if self.use_tail else (None, None)
+        self.xcd_cus, words, rest = _sweep_cu_config() if self.use_tail else (None, None, None)
         self.sweep_stream = ops.cu_masked_stream(dev, words) if words is not None else None
+        # with a CU-masked sweep the image and tail streams are confined to the CUs it leaves out (SIXDGS_SIDE_STREAMS_UNMASKED=1: anywhere).  Unconfined,
+        # their small workgroups keep landing on the sweep's CUs, and a persistent sweep workgroup needs its CU EMPTY (160 KB of LDS, every register):
+        # measured, the sweep of a batch then starts only when the previous tail's HBM-bound kernel has drained, or -- with no spare CU -- a sibling set
+        # starves for a whole round (profiles/r06_pipeline_ab.md)
+        confined = rest is not None and os.environ.get("SIXDGS_SIDE_STREAMS_UNMASKED") != "1"
+        self.image_stream = ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)
+        self.tail_stream = (ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)) if self.use_tail else None
         self._split_ok = None         # decided at the first submit: is there room for the second select workspace?
         self._tail_done = [None, None]        # event behind the tail that last used select workspace 0 / 1
         self._n = 0

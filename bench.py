@@ -532,8 +532,7 @@ def main():
         terms = {ops.MMA_F32: 1, ops.MMA_BF16X6: 6, ops.MMA_F16X3: 3, ops.MMA_F16X3_L32: 3}[mode]
         peak = PEAK_F32_MFMA_TFLOPS if mode == ops.MMA_F32 else PEAK_16BIT_MFMA_TFLOPS / terms
         out["roofline"] = {
-            "kernel": {ops.MMA_BF16X6: "k_logits_v2: q.K^T with fp32 operands split into 3 bf16 planes, 6 cross terms on "
-                                       "v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), LDS-DMA ring, online row stats, logits stored once",
+            "kernel": {ops.MMA_BF16X6: "k_logits<bf16x6>: q.K^T on fp32 keys, the operands split into 3 bf16 planes on the fly, 6 cross terms on v_mfma_f32_32x32x16_bf16 (fp32-equivalent result), online row stats, logits stored once",
                        ops.MMA_F16X3: ("k_logits_f16x<UB> (select path): K.Q^T (256 rays x 256 tokens per tile) with fp32 operands scaled by a power of two "
                                        "and split into 2 fp16 planes, 3 cross terms on v_mfma_f32_32x32x16_f16 (fp32-equivalent result), LDS-DMA "
                                        "rings; epilogue exp2 + token-sum butterfly, 16 B per ray and image leave the chip (no logits)"

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_score_select_split (the tail of a select batch on a second stream, CU-masked sweep streams); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_score_select_split (the tail of a select batch on a second stream, CU-masked sweep streams), the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -201,20 +201,16 @@ size_t sixdgs_ray_keys_workspace_bytes(int64_t r, int64_t max_chunk);
 int sixdgs_ray_keys(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
                     float* feat, float* key, void* ws, size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing the whole MLP chain of each chunk (2 025 472 algorithmic FLOP per ray) into `prof` */
-/* key_planes (optional, sixdgs_key_planes_bytes(r) bytes): the keys pre-split into three bf16 planes,
- * [R][12 k-slabs][3 planes][32] -- the operand format of the DMA-fed bf16x6 scorer kernel.  With key == NULL only
- * the planes are kept (2304 B per ray instead of 1536 B fp32). */
-/* mma_mode == SIXDGS_MMA_F16X3: key_planes are the scaled fp16 planes (sixdgs_key_planes_f16_bytes(r) bytes, 1536 B per
- * ray) and key_inv_scale[ceil(r/128)] (device, required) receives the per-tile reciprocal scales. */
+/* key_planes (optional; mma_mode F16X3 / F16X3_L32 / DEFAULT only, SIXDGS_E_UNSUPPORTED otherwise): the keys as scaled fp16 planes
+ * (sixdgs_key_planes_f16_bytes(r) bytes, 1536 B per ray) -- the operand of the DMA-fed scorer kernels and of the select path -- and
+ * key_inv_scale[ceil(r/128)] (device, required) receives the per-tile reciprocal scales.  With key == NULL only the planes are kept.
+ * (Rounds 1-5 also had a three-plane bf16 format for a bf16 x 6 plane scorer; kernel and format were removed in round 6, ABI 6.) */
 /* d_key_norm_max (device scalar, may be NULL; scaled fp16 planes only): *d_key_norm_max = max(*d_key_norm_max, max over these rays of
  * |key row|), rounded up -- the bound sixdgs_score_select / sixdgs_select_candidates take; zero it before the first chunk of a scene.
  * Free when k_proj writes the planes itself (its epilogue has the rows), one pass over the planes otherwise. */
 int sixdgs_ray_keys_ex(const float* ori, const float* dir, const float* rgb, int64_t r, const sixdgs_scorer_weights* w,
                        float* feat, float* key, void* key_planes, float* key_inv_scale, float* d_key_norm_max, void* ws,
                        size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof, int mma_mode);
-size_t sixdgs_key_planes_bytes(int64_t r);
-/* fp32 rows [rows][384] (row stride ld floats) -> bf16 planes [rows][12][3][32] (x = h + m + l exactly) */
-int sixdgs_split_planes(const float* src, int64_t rows, int64_t ld, void* planes, sixdgs_stream_t stream);
 /* fp32 rows -> scaled fp16 planes [rows][12][2][32] (1536 B per row) for SIXDGS_MMA_F16X3: every 128-row tile is scaled
  * by the power of two that puts its largest magnitude in [2^13, 2^14); d_inv_scale[ceil(rows/128)] (device) receives the
  * reciprocal scales.  Splitting a row range in chunks is valid when every chunk starts at a multiple of 128 rows. */
@@ -256,9 +252,9 @@ int sixdgs_score_topk(const float* q /*[B,256,384]*/, const int32_t* d_n_tok, in
                       float* val /*[B,topk]*/, float* row_stats /*[B,256,2] (max, sumexp) or NULL*/, void* ws,
                       size_t ws_bytes, sixdgs_stream_t stream);
 /* same, timing each launch of the logits kernel (2*T*384 algorithmic FLOP per ray and image) into `prof` */
-/* key_planes != NULL (and mma_mode != F32) selects a DMA-fed kernel; `key` (fp32) may then be NULL.  The planes must be in
- * the format of the mode: bf16 planes (sixdgs_split_planes) for BF16X6 / DEFAULT, scaled fp16 planes + d_key_scale (the
- * d_inv_scale of sixdgs_split_planes_f16 / sixdgs_ray_keys_ex) for F16X3. */
+/* key_planes != NULL in the F16X3 / F16X3_L32 / DEFAULT modes selects the DMA-fed kernel: scaled fp16 planes + d_key_scale (the d_inv_scale of
+ * sixdgs_split_planes_f16 / sixdgs_ray_keys_ex); `key` (fp32) may then be NULL.  SIXDGS_MMA_F32 / _BF16X6 score on `key` (fp32 MFMA chain / bf16 x 6
+ * with the split on the fly) and ignore the planes; planes without `key` in those modes: SIXDGS_E_UNSUPPORTED. */
 int sixdgs_score_topk_ex(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok /*host copy, for the FLOP count*/,
                          int batch, const float* key, const void* key_planes, const float* d_key_scale, int64_t r, int topk,
                          float* scores, int64_t* idx, float* val, float* row_stats, void* ws, size_t ws_bytes,

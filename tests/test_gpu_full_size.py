@@ -89,12 +89,14 @@ def test_scorer_invariants_at_full_size(full):
     # batch invariance: image 1 alone gives the same bits as inside the batch
     i1, v1, s1, _ = ops.score_topk(q[1:2].contiguous(), n_tok[1:2].contiguous(), None, 100, workspace=ws, key_planes=planes, key_scale=inv)
     assert torch.equal(i1[0], idx[1]) and torch.equal(s1[0], sc[1])
-    # an independent arithmetic scheme (3 bf16 planes x 6 terms, different kernel, different logits layout) picks the same rays
+    # an independent arithmetic scheme (fp32 keys from the bf16 x 6 dense layers, 3 bf16 planes x 6 terms split on the fly, different kernel, different
+    # logits layout) picks the same rays
     del s1
     ops.set_mma_mode(ops.MMA_BF16X6)
     try:
-        _, _, planes6 = ops.ray_keys(ori, dr, rgb, full["w"], want_key=False, want_planes=True)
-        i6, v6, s6, _ = ops.score_topk(q, n_tok, None, 100, workspace=ws, key_planes=planes6)
+        _, key6 = ops.ray_keys(ori, dr, rgb, full["w"])
+        i6, v6, s6, _ = ops.score_topk(q, n_tok, key6, 100, workspace=ws)
+        del key6
     finally:
         ops.set_mma_mode(ops.MMA_DEFAULT)
     assert float((s6 - sc).abs().max() / sc.abs().max()) < 1e-5

@@ -232,12 +232,16 @@ def scorer(request, ops, oracle, golden, syn):
     sd = syn.make_scorer_state_dict(0)
     rays = syn.make_rays(4096, 0)
     w = ops.PackedWeights({k: torch.from_numpy(v) for k, v in sd.items()}, "cuda")
-    feat, key, planes = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True, want_planes=True)
+    f16 = request.param in ("f16x3", "f16x3l32")
+    feat, key, *rest = ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_feat=True, want_planes=f16)
     ofeat, okey = oracle.ray_features(rays["ori"], rays["dir"], rays["rgb"], sd)
-    # bf16x6 / f16x3 modes score through the DMA-fed kernels on pre-split planes; f32 mode on the fp32 keys
-    kscale = None
-    if request.param in ("f16x3", "f16x3l32"):
-        planes, kscale = planes
+    # the f16x3 modes score through the DMA-fed kernels on pre-split planes; f32 and bf16x6 on the fp32 keys (key planes exist in ONE format since round 6)
+    planes = kscale = None
+    if not f16:
+        with pytest.raises(RuntimeError, match="fp16 x 3 modes only"):
+            ops.ray_keys(G(rays["ori"]), G(rays["dir"]), G(rays["rgb"]), w, want_planes=True)
+    if f16:
+        planes, kscale = rest[0]
         # the planes written chunk by chunk behind k_proj are those of a single split pass over the finished keys
         p2, s2 = ops.split_planes_f16(key)
         assert torch.equal(p2, planes) and torch.equal(s2, kscale)
@@ -250,7 +254,7 @@ def scorer(request, ops, oracle, golden, syn):
         assert rel_err(N(kfast), okey) < 5e-6                 # the chain's keys against the oracle ...
         assert rel_err(N(kfast), N(key)) < 2e-6               # ... and against the fp32-operand kernels' keys
     return dict(g=g, sd=sd, rays=rays, w=w, feat=feat, key=key, ofeat=ofeat, okey=okey, mode=request.param,
-                planes=planes if request.param != "f32" else None, kscale=kscale)
+                planes=planes, kscale=kscale)
 
 
 def test_a12_ray_encode(ops, oracle, scorer):
@@ -360,26 +364,26 @@ def test_score_topk_batched_and_grouped(ops, scorer, syn):
     assert (N(idx)[4] == np.arange(100)).all()            # all ties -> lowest indices
 
 
-def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
-    """x == h + m + l exactly for the 3-plane bf16 split; the three logits kernels (fp32 MFMA, bf16x6 with
-    on-the-fly split, bf16x6 DMA-fed on pre-split planes) agree to fp32 rounding and in their top-100."""
+def test_scorer_kernels_agree_and_fp16_planes_are_exact(ops, scorer, syn):
+    """The logits kernels (fp32 MFMA chain and bf16x6 with the split on the fly, both on fp32 keys; fp16 x 3 DMA-fed on scaled planes, with 24-bit and
+    fp32 logits) agree to fp32 rounding and in their top-100; the scaled fp16 planes reproduce the keys to 2^-22 of each tile's maximum; key planes
+    handed to a mode that scores on fp32 keys are ignored when `key` is there and refused when it is not."""
     key = scorer["key"]
-    pl = ops.split_planes(key).cpu().numpy().reshape(-1, 12, 3, 32, 2)
-    u16 = (pl[..., 0].astype(np.uint32) | (pl[..., 1].astype(np.uint32) << 8)) << 16
-    parts = u16.view(np.float32).astype(np.float64)                       # [R,12,3,32]
-    recon = parts.sum(axis=2).reshape(-1, 384)
-    assert (recon == N(key).astype(np.float64)).all()
-    assert (np.abs(parts[:, :, 1]) <= np.abs(parts[:, :, 0]) * 2.0 ** -8 + 1e-45).all()
     tok = syn.make_tokens(256, 5, 40.0)
     tokens, n_tok = ops.pad_tokens([G(tok)], "cuda")
     q = ops.q_proj(tokens, n_tok, scorer["w"])
     res = {}
     p16, s16 = ops.split_planes_f16(key)
     for name, mode, kp, ks in (("f32", ops.MMA_F32, None, None), ("b6", ops.MMA_BF16X6, None, None),
-                               ("b6dma", ops.MMA_BF16X6, ops.split_planes(key), None), ("f16x3", ops.MMA_F16X3, p16, s16),
+                               ("b6planes", ops.MMA_BF16X6, p16, s16), ("f16x3", ops.MMA_F16X3, p16, s16),
                                ("f16x3l32", ops.MMA_F16X3_L32, p16, s16)):
         ops.set_mma_mode(mode)
         res[name] = ops.score_topk(q, n_tok, key, 100, key_planes=kp, key_scale=ks)
+    for a, b in zip(res["b6"], res["b6planes"]):           # planes next to fp32 keys in a mode that scores on the keys: ignored
+        assert a is None or torch.equal(a, b)
+    ops.set_mma_mode(ops.MMA_BF16X6)
+    with pytest.raises(RuntimeError, match="fp32 keys"):
+        ops.score_topk(q, n_tok, None, 100, key_planes=p16, key_scale=s16)
     ops.set_mma_mode({"bf16x6": ops.MMA_BF16X6, "f16x3": ops.MMA_F16X3, "f16x3l32": ops.MMA_F16X3_L32, "f32": ops.MMA_F32}[scorer["mode"]])
     # the scaled fp16 planes reproduce the keys to 2^-22 relative to the largest key of each 128-ray tile
     kn = N(key).astype(np.float64)
@@ -393,7 +397,7 @@ def test_split_planes_is_exact_and_three_kernels_agree(ops, scorer, syn):
         assert 2.0 ** 13 <= np.abs(blk).max() / inv[t] < 2.0 ** 14
     # the 24-bit logits change no bit of the row statistics and move the scores by < 1e-6
     assert float((res["f16x3"][2] - res["f16x3l32"][2]).abs().max() / res["f16x3l32"][2].abs().max()) < 1e-6
-    for name in ("b6", "b6dma", "f16x3", "f16x3l32"):
+    for name in ("b6", "f16x3", "f16x3l32"):
         assert rel_err(N(res[name][2]), N(res["f32"][2])) < 5e-6, name
         assert (N(res[name][0]) == N(res["f32"][0])).all(), name
 
@@ -410,8 +414,7 @@ def test_scorer_on_tiny_ray_sets(ops, oracle, r):
     for mode in (ops.MMA_F16X3, ops.MMA_BF16X6, ops.MMA_F32):
         ops.set_mma_mode(mode)
         try:
-            kp, ks = (ops.split_planes_f16(G(key)) if mode == ops.MMA_F16X3 else
-                      ((ops.split_planes(G(key)), None) if mode == ops.MMA_BF16X6 else (None, None)))
+            kp, ks = ops.split_planes_f16(G(key)) if mode == ops.MMA_F16X3 else (None, None)
             idx, val, sc, _ = ops.score_topk(G(q), n_tok, G(key), 100, key_planes=kp, key_scale=ks)
         finally:
             ops.set_mma_mode(ops.MMA_DEFAULT)

@@ -44,7 +44,7 @@ def main():
     def planes_of(k):
         if a.mode == "f16x3":
             return ops.split_planes_f16(k)
-        return (ops.split_planes(k), None) if a.mode == "bf16x6" else (None, None)
+        return (None, None)            # f32 / bf16x6 score on the fp32 keys
 
     if a.select:
         return check_select(a, dd, ops, rank, world, dev, key, q, n, n_tok)
