@@ -246,16 +246,20 @@ class PoseStream:
       handle = ps.submit(images, gt)      # enqueue everything of this batch; returns at once
       c2w, sol = ps.collect(handle)       # later: the batch's poses on the host
 
-    Three streams (round 6; round 5 had the first two):
-      image stream  ViT-S/14 -> tokens, then the camera-up CNN of batch N + 1 (two hipGraphs, ~250 small launches);
-      sweep stream  q_proj, sample pre-pass and the matrix-core sweep -- the caller's stream, or (SIXDGS_SWEEP_CU_MASK) a CU-masked stream of its own;
-      tail stream   everything BEHIND the sweep of batch N: merge of the token partials, U, thresholds, candidates, exact re-score, top-k, pose solve, the
-                    batch's one D2H -- ~25 launches that keep a handful of CUs busy for ~1.3 ms.  In round 5 they sat between sweep N and pre-pass N + 1.
-    The select path then alternates between TWO workspaces (the tail of N reads one while N + 1 sweeps into the other); scenes that leave no room for
-    the second one keep round 5's order (tail on the sweep's stream).  A persistent sweep holds every CU it may use, so without a CU mask the sweep of
-    N + 1 is held until the tail of N has retired (what overlaps is that tail and the pre-pass of N + 1); with a mask the tail and the image side have
-    CUs of their own WHILE a sweep runs and nothing waits.  Poses are bit-identical to the unpipelined run: the same kernels on the same data.
-    SIXDGS_POSE_STREAM_TAIL=0: round 5's two streams.
+    With one batch submitted before the previous one is collected, (a) the host never sits between the GPU's last kernel of batch N and its
+    first of batch N + 1, and (b) the image side -- ~250 small kernels, ViT-S/14 + camera-up CNN -- runs on its OWN stream.
+    Round 6: the image side runs ONE BATCH FURTHER AHEAD than the scorer ("lead").  submit(N) enqueues the image side of batch N at once but the scoring of
+    batch N only when the next submit (or its collect) comes; in the loop `submit(N + 1); collect(N)` the ViT of N + 1 therefore has the whole of sweep N
+    and both windows around it to finish in, and `q_proj` of a batch never waits for its tokens.  Before, the ViT of N + 1 was enqueued together with the
+    scoring of N + 1: it had only the ~2 ms between two sweeps (a sweep holds every CU: 2 waves x 256 registers per SIMD, 160 KB of LDS), did not fit
+    (ViT ~ 2.0 ms against a 1.3 ms tail), and what was left of it sat on the critical path in front of the next pre-pass.  SIXDGS_POSE_STREAM_LEAD=0 undoes it.
+    Poses are bit-identical to the unpipelined run: the same kernels on the same data in the same order per batch.
+
+    Opt-in (measured in round 6, `profiles/r06_pipeline_ab.md`; neither is faster than the default, both stay tested):
+      SIXDGS_POSE_STREAM_TAIL=1   a third stream for everything BEHIND the sweep of a batch (merge of the token partials, U, thresholds, candidates, exact
+                                  re-score, top-k, pose solve, D2H) beside the next batch's pre-pass, two select workspaces (sixdgs_score_select_split);
+      SIXDGS_SWEEP_CU_MASK=<n>x<m> (with the tail stream) the sweep on a CU-masked stream that leaves n CUs of the last m XCDs to the image and tail streams,
+                                  which are confined to exactly those (SIXDGS_SIDE_STREAMS_UNMASKED=1: not confined).
 
     Inputs of batch N must exist before submit(N - 1) was called, or be produced on `ps.image_stream` (uploads under
     `with torch.cuda.stream(ps.image_stream)`): the image stream does not wait for the caller's stream beyond that point."""
@@ -265,27 +269,28 @@ class PoseStream:
         self.workspace, self.images_in_flight = workspace, images_in_flight
         dev = rays_ori.device
         self._fence = None            # recorded on the sweep stream at the START of the previous submit
-        self.use_tail = os.environ.get("SIXDGS_POSE_STREAM_TAIL", "1") != "0"
+        self.lead = os.environ.get("SIXDGS_POSE_STREAM_LEAD", "1") != "0"
+        self.use_tail = os.environ.get("SIXDGS_POSE_STREAM_TAIL", "0") == "1"
         self.xcd_cus, words, rest = _sweep_cu_config() if self.use_tail else (None, None, None)
         self.sweep_stream = ops.cu_masked_stream(dev, words) if words is not None else None
-        # with a CU-masked sweep the image and tail streams are confined to the CUs it leaves out (SIXDGS_SIDE_STREAMS_UNMASKED=1: anywhere).  Unconfined,
-        # their small workgroups keep landing on the sweep's CUs, and a persistent sweep workgroup needs its CU EMPTY (160 KB of LDS, every register):
-        # measured, the sweep of a batch then starts only when the previous tail's HBM-bound kernel has drained, or -- with no spare CU -- a sibling set
-        # starves for a whole round (profiles/r06_pipeline_ab.md)
+        # with a CU-masked sweep the image and tail streams are confined to the CUs it leaves out (SIXDGS_SIDE_STREAMS_UNMASKED=1: anywhere): unconfined,
+        # their small workgroups keep landing on the sweep's CUs, and a persistent sweep workgroup needs its CU EMPTY
         confined = rest is not None and os.environ.get("SIXDGS_SIDE_STREAMS_UNMASKED") != "1"
         self.image_stream = ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)
         self.tail_stream = (ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)) if self.use_tail else None
-        self._split_ok = None         # decided at the first submit: is there room for the second select workspace?
+        self._split_ok = None         # decided at the first scoring: is there room for the second select workspace?
         self._tail_done = [None, None]        # event behind the tail that last used select workspace 0 / 1
-        self._n = 0
+        self._n = 0                   # batches scored so far
+        self._waiting = None          # the handle whose image side is enqueued and whose scoring is not (lead)
 
     @torch.no_grad()
     def submit(self, images, gt_c2w=None, profile=None, tokens=None, up=None):
         caller = torch.cuda.current_stream()
         main = self.sweep_stream if self.sweep_stream is not None else caller
         side = self.image_stream
-        if main is not caller and self._n == 0:
+        if main is not caller and self._n == 0 and self._waiting is None:
             main.wait_stream(caller)             # the scene's key planes, weights and rays were produced on the caller's stream
+        handle = {"sol": None, "host": None, "done": None, "gt": gt_c2w, "profile": profile, "ready": None, "up_ready": None}
         if tokens is None:
             if self._fence is None:
                 side.wait_stream(caller)
@@ -300,28 +305,44 @@ class PoseStream:
                 if res is not None:
                     # the graphs' outputs are STATIC buffers, rewritten by the next replay: this batch keeps its own copies (1.6 MB at 4 images).
                     # The tokens are ready when the ViT graph is; the camera-up CNN (needed only by the pose solve at the END of the batch) is replayed
-                    # behind them and no longer sits on the path to the sweep
+                    # behind them and does not sit on the path to the sweep
                     tk = res[0]
                     tokens = type(tk)(tk.feats.clone(), tk.pe) if hasattr(tk, "feats") else tk.clone()
-                    ready = torch.cuda.Event()
-                    ready.record(side)
+                    handle["ready"] = torch.cuda.Event()
+                    handle["ready"].record(side)
                     up = cache.cnn().clone()
-                    up_ready = torch.cuda.Event()
-                    up_ready.record(side)
+                    handle["up_ready"] = torch.cuda.Event()
+                    handle["up_ready"].record(side)
                 else:
                     imgs_f, masks = prepare_images_device(images)
                     tokens, fmaps = self.idm.image_tokens(imgs_f, masks)
                     up = self.idm.camera_up(fmaps)
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                    up_ready = ready
-            main.wait_event(ready)
+                    handle["ready"] = handle["up_ready"] = torch.cuda.Event()
+                    handle["ready"].record(side)
+        else:
+            handle["injected"] = torch.cuda.Event()     # injected tokens / camera-up vectors come from the caller's stream
+            handle["injected"].record(caller)
+        handle["tokens"], handle["up"] = tokens, up
+        prev, self._waiting = self._waiting, handle
+        if prev is not None:
+            self._score(prev)
+        if not self.lead:
+            self._score(handle)
+            self._waiting = None
+        return handle
+
+    def _score(self, handle):
+        """Second half of a batch: q_proj, sample pre-pass, sweep, tail, pose solve, the batch's one D2H -- everything behind the tokens."""
+        caller = torch.cuda.current_stream()
+        main = self.sweep_stream if self.sweep_stream is not None else caller
+        side = self.image_stream
+        tokens, up, gt_c2w = handle["tokens"], handle["up"], handle["gt"]
+        if handle["ready"] is not None:
+            main.wait_event(handle["ready"])
             for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))):
                 t.record_stream(main)          # allocated on the image stream, read on the sweep's
-        else:
-            up_ready = None
-            if main is not caller:
-                main.wait_stream(caller)       # injected tokens / camera-up vectors come from the caller's stream
+        elif main is not caller:
+            main.wait_event(handle["injected"])
         b = len(tokens) if not torch.is_tensor(tokens) else tokens.shape[0]
         if self._split_ok is None:
             self._split_ok = bool(self.use_tail and self.idm.second_select_workspace_fits(b, self.rays[0].shape[0], self.rays[0].device, self.k))
@@ -335,7 +356,7 @@ class PoseStream:
             split = ops.SelectSplit(self.tail_stream, wait_event=self._tail_done[slot ^ 1] if self.sweep_stream is None else None, xcd_cus=self.xcd_cus)
         with torch.cuda.stream(main):
             idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
-                                                         images_in_flight=self.images_in_flight, profile=profile, defer_status=True, split=split,
+                                                         images_in_flight=self.images_in_flight, profile=handle["profile"], defer_status=True, split=split,
                                                          ws_slot=slot)
         tail = self.tail_stream if self._split_ok else main
         if tail is not main:
@@ -344,9 +365,9 @@ class PoseStream:
             for t in [idx, weights] + ([pend["status"], pend["q"], pend["n_tok"]] if pend is not None else []):
                 t.record_stream(tail)          # allocated on the sweep's stream, read by the tail
         with torch.cuda.stream(tail):
-            if up_ready is not None:
-                tail.wait_event(up_ready)
-            if tail is not side and up is not None:
+            if handle["up_ready"] is not None:
+                tail.wait_event(handle["up_ready"])
+            if tail is not side and up is not None and handle["up_ready"] is not None:
                 up.record_stream(tail)
             if gt_c2w is not None and tail is not caller:
                 gt_c2w.record_stream(tail)
@@ -360,11 +381,15 @@ class PoseStream:
             done.record(tail)
         if self._split_ok:
             self._tail_done[slot] = done
-        return {"sol": sol, "host": host, "done": done, "keep": full}
+        handle.update(sol=sol, host=host, done=done, keep=full)
 
     @torch.no_grad()
     def collect(self, handle):
         """-> (c2w [B,4,4] on the host, sol).  Images the select path refused are re-done here by the two-pass scorer (rare)."""
+        if handle["done"] is None:             # its scoring has not been enqueued yet (no later submit came): now
+            if self._waiting is handle:
+                self._waiting = None
+            self._score(handle)
         handle["done"].synchronize()
         return resolve_poses(self.idm, handle["sol"], handle["host"][:, :17]), handle["sol"]
 

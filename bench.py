@@ -144,6 +144,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    if os.environ.get("SIXDGS_BENCH_FORCE_DEVICE") is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # test hook: several ranks share ONE GPU.  Every process would open 4 hardware queues (+ SDMA): eight of them oversubscribe the device's queue slots
+        # and the scheduler starts preempting queues -- under which the runtime aborted 1 run in 40 with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION inside a
+        # stock PyTorch copy kernel (profiles/r06_eight_ranks_sigabrt.md).  One hardware queue per process keeps the rehearsal inside what the device runs natively.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     import torch
     pkg = importlib.import_module("6dgs_amd")
     syn = importlib.import_module("6dgs_amd.synthetic")

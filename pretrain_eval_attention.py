@@ -12,6 +12,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 if __name__ == "__main__":
+    if os.environ.get("SIXDGS_FORCE_DEVICE") is not None and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")      # test hook, several ranks on ONE GPU: see bench.py main() / profiles/r06_eight_ranks_sigabrt.md
     import torch
     torch.manual_seed(71170)            # the reference seeds here too (pretrain_eval_attention.py:252-253)
     importlib.import_module("6dgs_amd.pretrain_eval_attention").main()

@@ -18,18 +18,11 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _run_eight(cmd, env, timeout):
-    """Eight processes sharing ONE GPU (eight HIP contexts, gloo between them) is a rehearsal outside what the runtime is exercised for: in one of ~8 runs
-    on one box an IDLE rank (no views of its own) died with SIGABRT and no Python traceback, five identical re-runs passed (tools/round5_calls/r5_call14.sh).
-    The rehearsal checks this build's rank logic, so a run that dies that way is repeated once -- and said so."""
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    if p.returncode != 0 and "SIGABRT" in (p.stderr + p.stdout):
-        print("8-rank run aborted in the runtime (SIGABRT); repeating once:\n" + p.stderr[-800:])
-        cmd = list(cmd)
-        if "--master-port" in cmd:                       # a fresh rendezvous port for the second attempt
-            i = cmd.index("--master-port") + 1
-            cmd[i] = str(int(cmd[i]) + 1)
-        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    return p
+    """Eight processes sharing ONE GPU (gloo between them).  Round 5 saw one such run in ~8 abort and repeated it once; round 6 found the abort to be the HSA
+    runtime's queue-error callback -- HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION raised by the GPU inside a stock PyTorch copy kernel of a WORKING rank, 1 run in
+    40 -- under eight processes x four hardware queues on one device (profiles/r06_eight_ranks_sigabrt.md).  The launchers now give every rank ONE hardware
+    queue when ranks are forced onto one device (GPU_MAX_HW_QUEUES=1: 40 of 40 runs clean), and the retry is gone: a run that dies fails the test."""
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def _run(cmd, env=None, timeout=400):
