@@ -64,10 +64,6 @@ SIGNATURES = {
     "sixdgs_score_topk_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile), i32]),
     "sixdgs_score_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_score_select": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp, C.POINTER(Profile)]),
-    "sixdgs_score_select_split": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, C.POINTER(Profile)]),
-    "sixdgs_stream_create_cu_mask": (i32, [vp, i32, C.POINTER(vp)]),
-    "sixdgs_stream_destroy": (i32, [vp]),
-    "sixdgs_debug_wg_placement": (i32, [i32, i64, vp, vp]),
     "sixdgs_key_planes_norm_max": (i32, [vp, vp, i64, vp, vp]),
     "sixdgs_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_select_candidates_workspace_bytes": (sz, [i64, i32, i32, i32]),

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <cstdlib>
+#include <cstdio>
 #include "gemm_kernel.h"
 #include "sweep_plan.h"
 
@@ -151,12 +152,6 @@ struct LogitsF16Args {
   unsigned sib_extra;    // arrivals a set waits for beyond its members: 0.  (1 = SIXDGS_SIBLING_SYNC=3, the test of the bounded wait: a sibling never shows up)
   int q_quarter_scales;  // 0: qinv [B][2], one scale per 128-token half (k_split_tiles_f16); 1: qinv [B][4], one per 64-token quarter (k_split_q_slots:
                          // the select sweep's packed slots, where the quarters of a tile belong to different images)
-  // Persistent sets on a CU-MASKED stream (round 6; all zero = the whole device, xcd_remap over the grid): xcd_wgs[x] = workgroups of this launch that
-  // WORK on XCD x (a multiple of nb: no sibling set straddles two XCDs), xcd_slots = the largest of them.  The grid is 8 x xcd_slots; workgroup i is
-  // dispatched to XCD i % 8 as its (i / 8)-th there, the FIRST xcd_slots - xcd_wgs[x] of an XCD leave at once, so that an XCD whose stream-visible
-  // CUs are fewer than xcd_slots never holds a workgroup back until a persistent one retires.
-  unsigned char xcd_wgs[8];
-  int xcd_slots;
 };
 // what the kernel leaves behind for each tile
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
@@ -220,7 +215,8 @@ constexpr int kBNX = 256;                // rays per tile
 constexpr int kSiblingSyncDefault = 1;
 constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
 constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
-constexpr int kSweepMaxImages = 8;      // images per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  0 / SIXDGS_SWEEP_MAX_IMAGES=0: no cap
+constexpr int kSweepMaxImages = 8;      // 256-token SLOTS per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  SIXDGS_SWEEP_MAX_IMAGES=n overrides (the name is
+                                        // round 4's, when a slot held one image); n <= 0 means "as many as the slot table holds": launches of 21, a last one of up to 31 (sweep_plan.h) -- NOT one launch for any batch
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
@@ -236,17 +232,7 @@ template <int ABL, int OUT, bool PERS = false>
 __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   constexpr bool L24 = OUT == kOutL24;
   __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
-  unsigned w;
-  if (PERS && A.xcd_slots > 0) {      // CU-masked stream: per-XCD workgroup counts (see LogitsF16Args)
-    const unsigned x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned idle = (unsigned)A.xcd_slots - (unsigned)A.xcd_wgs[x];
-    if (slot < idle) return;
-    unsigned base = 0;
-    for (unsigned y = 0; y < x; ++y) base += A.xcd_wgs[y];
-    w = base + slot - idle;
-  } else {
-    w = xcd_remap(blockIdx.x, gridDim.x);
-  }
+  const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   const int bl = (int)(w % (unsigned)A.nb);
   const int set = (int)(w / (unsigned)A.nb);        // the ray-tile group (one-shot grid) or the sibling set (persistent grid)
   const int b = A.b0 + bl;
@@ -2120,7 +2106,12 @@ size_t sixdgs_select_candidates_workspace_bytes(int64_t r, int batch, int topk, 
 
 // slots per launch of the packed sweep (SIXDGS_SWEEP_MAX_IMAGES; before round 5 it counted images -- a slot then held one image)
 static int sweep_slot_cap() {
-  static const int cap = [] { const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES"); return e ? atoi(e) : kSweepMaxImages; }();
+  static const int cap = [] {
+    const char* e = getenv("SIXDGS_SWEEP_MAX_IMAGES");
+    const int v = e ? atoi(e) : kSweepMaxImages;
+    if (e && v <= 0) fprintf(stderr, "6dgs_amd: SIXDGS_SWEEP_MAX_IMAGES=%s: launches of %d slots (the slot table's limit), a last one of up to %d -- not one launch per batch\n", e, kSweepMaxSlots * 2 / 3, kSweepMaxSlots * 2 / 3 + kSweepMaxSlots / 3);
+    return v;
+  }();
   return cap;
 }
 
@@ -2183,20 +2174,9 @@ int sixdgs_select_begin(const float* q, const int32_t* d_n_tok, const int32_t* h
   return sixdgs_select_prepare(w.stats, d_n_tok, batch, r_sample, r_total, ctok, gsum, stream);
 }
 
-}  // extern "C"
-
-namespace {
-// What a caller of the SPLIT select path hands over (sixdgs_score_select_split): the tail of the batch goes to a second stream.
-struct SelectSplit {
-  hipStream_t tail = nullptr;        // merge of the token partials, U = sum of the quarter rows, candidates, re-score, top-k: here (nullptr: on the sweep's stream)
-  hipEvent_t sweep_done = nullptr;   // recorded on the sweep's stream behind every sweep launch; the tail stream waits for it
-  hipEvent_t sweep_wait = nullptr;   // the sweep (not the sample pre-pass before it) waits for this event, e.g. the previous batch's tail
-  const unsigned char* xcd_cus = nullptr;   // [8] CUs of each XCD the sweep's stream may use (a CU-masked stream), nullptr = all
-};
-
-int select_sweep_impl(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                      const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
-                      void* ws, size_t ws_bytes, hipStream_t s, const SelectSplit& sp, sixdgs_profile* prof) {
+int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
+                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
+                        void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
   SDG_CHECK_ARG(batch >= 0 && batch <= 32767 && r >= 1 && u_stride >= sdg_cdiv(r, 256) * 256 && (u_stride % 4) == 0 && (!u_tile_max || (u_stride % 256) == 0));
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && key_planes && d_key_scale && ctok && gsum && u && ws && ((uintptr_t)key_planes % 16) == 0 &&
@@ -2209,50 +2189,24 @@ int select_sweep_impl(const float* q, const int32_t* d_n_tok, const int32_t* h_n
   // Round 5: the images of a launch are PACKED into the slots by their token counts (sweep_plan.h) -- two views of <= 128 tokens or four of <= 64 share a
   // 256-row tile -- so the matrix work AND the key stream per image follow the tokens the mask kept, as the reference's cost does
   // (backbone.py:86-114, identification_module.py:80-82).  Results do not depend on grouping or packing (tests/test_gpu_select.py, test_gpu_full_size.py).
-  // Round 6: with a tail stream (SelectSplit) everything behind a sweep launch -- the merge of its token partials into gsum, U = the sum of the quarter
-  // rows -- is enqueued THERE behind an event, so that the next launch (or the next batch's pre-pass and sweep, on another workspace) follows the sweep
-  // at once.  The launches of a batch then use DISJOINT slot ranges of the per-slot fields (q planes, ctok rows, token partials, ub rows): launch l + 1 may
-  // write while the tail of launch l still reads.  (Slots of all launches together <= batch: a launch of n images fills at most n slots.)
-  const bool split = sp.tail != nullptr && sp.tail != s;
-  hipStream_t st = split ? sp.tail : s;
-  SDG_CHECK_ARG(!split || sp.sweep_done != nullptr);
+  hipStream_t s = sdg_stream(stream);
   SelectWs w;
   if (!select_ws(ws, ws_bytes, r, batch, 1, 8, &w)) return SIXDGS_E_WORKSPACE;
   const int n_groups = f16x_groups(r);
-  int sb = 0;                          // first slot of this launch within the per-slot fields (split mode; otherwise every launch starts at 0)
   for (const SweepSlots& T : sweep_pack(h_n_tok, batch, sweep_slot_cap())) {
     const int ns = T.n_slots;
     double tok = 0.0;
     for (int k = 0; k < T.n_images; ++k) tok += h_n_tok ? (double)(h_n_tok[T.img[k]] < 0 ? 0 : (h_n_tok[T.img[k]] > kT ? kT : h_n_tok[T.img[k]])) : (double)kT;
-    SDG_CHECK_ARG(sb + ns <= batch);
-    char* const qplanes = w.qplanes + (size_t)sb * w.qpl_img;
-    float* const qinv = w.qinv + 4 * sb;
-    float* const ctok_slot = w.ctok_slot + (size_t)sb * kT;
-    int* const slot_rows = w.slot_rows + sb;
-    float* const partial = w.partial + (size_t)sb * n_groups * kT * 2;
-    float* const ub = w.ub + (size_t)sb * 4 * w.p.stride;
     if (ns > 0) {
-      hipLaunchKernelGGL(k_split_q_slots, dim3((unsigned)(4 * ns)), dim3(256), 0, s, q, d_n_tok, T, qplanes, qinv, ctok, ctok_slot, slot_rows);
-      LogitsF16Args V = select_args(slot_rows, ns, w, key_planes, d_key_scale, r);
-      V.qp = qplanes;
-      V.qinv = qinv;
-      V.partial = partial;
+      hipLaunchKernelGGL(k_split_q_slots, dim3((unsigned)(4 * ns)), dim3(256), 0, s, q, d_n_tok, T, w.qplanes, w.qinv, ctok, w.ctok_slot, w.slot_rows);
+      LogitsF16Args V = select_args(w.slot_rows, ns, w, key_planes, d_key_scale, r);
       V.q_quarter_scales = 1;
-      V.ctok = ctok_slot;
-      V.ub = ub;
+      V.ctok = w.ctok_slot;
+      V.ub = w.ub;
       V.ub_stride = w.p.stride;
       // algorithmic work: 2*T*384 FLOP per ray and image; bytes: the key planes once per launch + 16 B of partial sums per ray and image
       unsigned grid = (unsigned)(V.n_groups * ns);
-      int cus = sibling_sync_cus();
-      int xcd_wgs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xcd_slots = 0;
-      if (cus > 0 && sp.xcd_cus) {          // a CU-masked stream: whole sibling sets per XCD on the CUs it may use
-        cus = 0;
-        for (int x = 0; x < 8; ++x) {
-          xcd_wgs[x] = ns > 0 ? (int)sp.xcd_cus[x] / ns * ns : 0;
-          cus += xcd_wgs[x];
-          xcd_slots = xcd_wgs[x] > xcd_slots ? xcd_wgs[x] : xcd_slots;
-        }
-      }
+      const int cus = sibling_sync_cus();
       // (persistent sets leave cus % ns CUs idle: only when that is at most 1/16 of the chip -- e.g. not for 100 slots per launch)
       if (cus > 0 && ns >= 2 && cus / ns >= 1 && (cus % ns) * 16 <= cus && w.p.topk_bytes >= (size_t)(cus / ns) * sizeof(unsigned)) {
         // persistent sibling sets in lock-step (see the kernel): at most one workgroup per CU, so that every sibling is resident
@@ -2262,13 +2216,7 @@ int select_sweep_impl(const float* q, const int32_t* d_n_tok, const int32_t* h_n
         V.sib_period = kSibPeriod;
         if (V.sib_sync && hipMemsetAsync(V.sib_sync, 0, (size_t)V.n_sets * sizeof(unsigned), s) != hipSuccess) return (int)hipGetLastError();
         grid = (unsigned)(V.n_sets * ns);
-        if (xcd_slots > 0 && V.n_sets == cus / ns) {      // (fewer ray-tile groups than sets: a small scene, the plain grid serves)
-          for (int x = 0; x < 8; ++x) V.xcd_wgs[x] = (unsigned char)xcd_wgs[x];
-          V.xcd_slots = xcd_slots;
-          grid = (unsigned)(8 * xcd_slots);
-        }
       }
-      if (sp.sweep_wait && sb == 0 && hipStreamWaitEvent(s, sp.sweep_wait, 0) != hipSuccess) return (int)hipGetLastError();
       SdgProfileScope scope(prof, s, 2.0 * tok * SIXDGS_D * (double)r, (double)r * (kRowF + T.n_images * 16.0));
       auto kern = V.n_sets > 0 ? k_logits_f16x<0, kOutUB, true> : k_logits_f16x<0, kOutUB, false>;
 #ifdef SIXDGS_ABLATION   // timing / power experiments only (tools/power_trace.py abl<N> on a private -DSIXDGS_ABLATION build): the sweep with parts compiled out
@@ -2283,26 +2231,12 @@ int select_sweep_impl(const float* q, const int32_t* d_n_tok, const int32_t* h_n
 #endif
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, V);
     }
-    if (split) {
-      if (hipEventRecord(sp.sweep_done, s) != hipSuccess || hipStreamWaitEvent(st, sp.sweep_done, 0) != hipSuccess) return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, st, partial, n_groups, T, (float*)nullptr, gsum);
-    hipLaunchKernelGGL(k_sel_finish_slots, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)T.n_images), dim3(256), 0, st, ub, w.p.stride, u_stride, d_n_tok, T, r, u,
+    hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, s, w.partial, n_groups, T, (float*)nullptr, gsum);
+    hipLaunchKernelGGL(k_sel_finish_slots, dim3((unsigned)sdg_cdiv(r, 1024), (unsigned)T.n_images), dim3(256), 0, s, w.ub, w.p.stride, u_stride, d_n_tok, T, r, u,
                        u_tile_max, u_stride / 256);
-    if (split) sb += ns;
   }
   SDG_LAUNCH_OK();
   return 0;
-}
-}  // namespace
-
-extern "C" {
-
-int sixdgs_select_sweep(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                        const float* d_key_scale, int64_t r, const float* ctok, float* gsum, float* u, int64_t u_stride, float* u_tile_max,
-                        void* ws, size_t ws_bytes, sixdgs_stream_t stream, sixdgs_profile* prof) {
-  return select_sweep_impl(q, d_n_tok, h_n_tok, batch, key_planes, d_key_scale, r, ctok, gsum, u, u_stride, u_tile_max, ws, ws_bytes, sdg_stream(stream),
-                           SelectSplit(), prof);
 }
 
 int sixdgs_key_planes_norm_max(const void* planes, const float* d_scale, int64_t rows, float* d_norm_max, sixdgs_stream_t stream) {
@@ -2411,19 +2345,17 @@ size_t sixdgs_score_select_workspace_bytes(int64_t r, int batch, int topk, int m
                           sdg_align((size_t)max_candidates * sizeof(int64_t)) + 256);
 }
 
-static int score_select_impl(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                             const float* d_key_scale, const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale,
-                             int64_t r_sample, int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
-                             sixdgs_stream_t stream, const SelectSplit& sp, sixdgs_profile* prof) {
+int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
+                        const float* d_key_scale, const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale,
+                        int64_t r_sample, int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
+                        sixdgs_stream_t stream, sixdgs_profile* prof) {
   SDG_CHECK_ARG(r >= 1 && r_sample >= 1 && r_sample <= r && batch >= 0 && topk >= 1 && topk <= 1024 && max_candidates >= topk &&
                 max_candidates <= (1 << 20) && (max_candidates % 8) == 0);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(q && d_n_tok && d_key_norm_max && idx && val && d_status && ws && ((uintptr_t)ws % 256) == 0);
-  const bool split = sp.tail != nullptr && sp.tail != sdg_stream(stream);
-  sixdgs_stream_t tail = split ? (sixdgs_stream_t)sp.tail : stream;
   int64_t bg = batch > 4096 ? 4096 : batch;
   while (bg >= 1 && sixdgs_score_select_workspace_bytes(r, (int)bg, topk, max_candidates) > ws_bytes) --bg;
-  if (bg < 1 || (split && bg < batch)) return SIXDGS_E_WORKSPACE;      // (split: the whole batch in one group -- a second group would reuse the first one's fields under its tail)
+  if (bg < 1) return SIXDGS_E_WORKSPACE;
   bg = sdg_cdiv(batch, sdg_cdiv(batch, bg));
   const size_t stride = (size_t)sdg_cdiv(r, 256) * 256;
   const size_t stage = sdg_align(sixdgs_select_workspace_bytes(r, (int)bg, topk, max_candidates));
@@ -2440,79 +2372,15 @@ static int score_select_impl(const float* q, const int32_t* d_n_tok, const int32
     const int32_t* ng = d_n_tok + b0;
     int st = sixdgs_select_begin(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, sample_planes, d_sample_scale, r_sample, r, ctok, gsum, ws, stage, stream);
     if (st) return st;
-    st = select_sweep_impl(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, utm, ws, stage,
-                           sdg_stream(stream), sp, prof);
+    st = sixdgs_select_sweep(qg, ng, h_n_tok ? h_n_tok + b0 : nullptr, nb, key_planes, d_key_scale, r, ctok, gsum, u, (int64_t)stride, utm, ws, stage,
+                             stream, prof);
     if (st) return st;
-    st = sixdgs_select_candidates(u, (int64_t)stride, r, utm, qg, ng, nb, gsum, d_key_norm_max, nullptr, topk, max_candidates, cand, count, ws, stage, tail);
+    st = sixdgs_select_candidates(u, (int64_t)stride, r, utm, qg, ng, nb, gsum, d_key_norm_max, nullptr, topk, max_candidates, cand, count, ws, stage, stream);
     if (st) return st;
     st = sixdgs_select_rescore(qg, ng, nb, key_planes, d_key_scale, 0, ctok, gsum, cand, count, r, topk, max_candidates, 0,
-                               idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, tail);
+                               idx + (int64_t)b0 * topk, val + (int64_t)b0 * topk, d_status + b0, ws, stage, stream);
     if (st) return st;
   }
-  return 0;
-}
-
-int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                        const float* d_key_scale, const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale,
-                        int64_t r_sample, int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
-                        sixdgs_stream_t stream, sixdgs_profile* prof) {
-  return score_select_impl(q, d_n_tok, h_n_tok, batch, key_planes, d_key_scale, d_key_norm_max, r, sample_planes, d_sample_scale, r_sample, topk,
-                           max_candidates, idx, val, d_status, ws, ws_bytes, stream, SelectSplit(), prof);
-}
-
-int sixdgs_score_select_split(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes,
-                              const float* d_key_scale, const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale,
-                              int64_t r_sample, int topk, int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes,
-                              sixdgs_stream_t stream, sixdgs_stream_t tail_stream, void* sweep_done_event, void* sweep_wait_event,
-                              const uint8_t* h_sweep_xcd_cus, sixdgs_profile* prof) {
-  SDG_CHECK_ARG(tail_stream == nullptr || tail_stream == stream || sweep_done_event != nullptr);
-  if (h_sweep_xcd_cus)
-    for (int x = 0; x < 8; ++x) SDG_CHECK_ARG(h_sweep_xcd_cus[x] <= 64);
-  SelectSplit sp;
-  sp.tail = tail_stream ? sdg_stream(tail_stream) : nullptr;
-  sp.sweep_done = (hipEvent_t)sweep_done_event;
-  sp.sweep_wait = (hipEvent_t)sweep_wait_event;
-  sp.xcd_cus = h_sweep_xcd_cus;
-  return score_select_impl(q, d_n_tok, h_n_tok, batch, key_planes, d_key_scale, d_key_norm_max, r, sample_planes, d_sample_scale, r_sample, topk,
-                           max_candidates, idx, val, d_status, ws, ws_bytes, stream, sp, prof);
-}
-
-// ---- CU-masked streams (round 6) -------------------------------------------------------------------------------------------------
-// A persistent sweep holds every CU it is given (2 waves of 256 registers per SIMD, 160 KB of LDS): whatever else is ready -- the tail of the previous
-// batch, the ViT of the next -- waits until it retires.  A stream created with a CU mask keeps the sweep off a few CUs; those serve the other streams
-// while it runs.  Created and destroyed through the library so that the stream belongs to the HIP runtime the kernels run on.
-int sixdgs_stream_create_cu_mask(const uint32_t* h_mask, int words, sixdgs_stream_t* out) {
-  SDG_CHECK_ARG(h_mask && words >= 1 && words <= 64 && out);
-  hipStream_t s = nullptr;
-  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, h_mask);
-  if (e != hipSuccess) return (int)e;
-  *out = (sixdgs_stream_t)s;
-  return 0;
-}
-
-int sixdgs_stream_destroy(sixdgs_stream_t stream) {
-  SDG_CHECK_ARG(stream);
-  return (int)hipStreamDestroy(sdg_stream(stream));
-}
-
-// Where the workgroups of a launch on `stream` run: out[i] = (XCC_ID << 16) | (HW_ID & 0xffff) of workgroup i, each spinning `spin_cycles` so that
-// a grid of one workgroup per CU is resident at once (tools/probe_cumask.py: which mask bit is which CU of which XCD).
-__global__ void __launch_bounds__(512, 1) k_wg_placement(unsigned* __restrict__ out, long long spin_cycles) {
-  __shared__ char hog[kLdsX];            // the sweep's LDS footprint: one workgroup per CU
-  if (threadIdx.x == 0) {
-    hog[0] = 1;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);      // HW_REG_XCC_ID [3:0]
-    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);       // HW_REG_HW_ID [15:0]: wave, simd, pipe, cu [11:8], sh [12], se [15:13]
-    out[blockIdx.x] = (xcc << 16) | (hw & 0xffffu);
-  }
-  const long long t0 = (long long)__builtin_readcyclecounter();
-  while ((long long)__builtin_readcyclecounter() - t0 < spin_cycles) __builtin_amdgcn_s_sleep(8);
-}
-
-int sixdgs_debug_wg_placement(int n_wgs, int64_t spin_cycles, uint32_t* d_out, sixdgs_stream_t stream) {
-  SDG_CHECK_ARG(n_wgs >= 1 && n_wgs <= 65536 && d_out && spin_cycles >= 0);
-  hipLaunchKernelGGL(k_wg_placement, dim3((unsigned)n_wgs), dim3(512), 0, sdg_stream(stream), d_out, (long long)spin_cycles);
-  SDG_LAUNCH_OK();
   return 0;
 }
 

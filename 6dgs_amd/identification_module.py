@@ -129,7 +129,7 @@ class IdentificationModule(torch.nn.Module):
         if not same:
             self._key_cache = self._key_cache_rays = None        # drop the old planes before allocating the new ones
             if ops.get_arena() is not None:                      # ... and with an arena everything else that was carved from it for the old scene
-                self._select_ws = self._select_ws_b = self._stream_sample = None
+                self._select_ws = self._stream_sample = None
                 ops.get_arena().reset(self)
             r = rays_ori.shape[0]
             planes_mode = mode in ops.F16_MODES
@@ -207,7 +207,7 @@ class IdentificationModule(torch.nn.Module):
     def invalidate_caches(self):
         """Drops the packed weights and the key cache (needed only after mutating weights or rays through `.data` tricks
         that bypass the version counters; a NEW ray tensor always misses the cache: entries are keyed on tensor identity)."""
-        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._select_ws_b = self._stream_sample = self._peq = None
+        self._packed = self._key_cache = self._key_cache_rays = self._select_ws = self._stream_sample = self._peq = None
         if ops.get_arena() is not None:       # the planes / workspaces just dropped were carved from it (an arena serves ONE module: ops.Arena)
             ops.get_arena().reset(self)
 
@@ -239,22 +239,17 @@ class IdentificationModule(torch.nn.Module):
     @torch.no_grad()
     def score_tokens(self, token_list: List[torch.Tensor], rays_ori, rays_dir, rays_rgb, rays_to_output: int = 100,
                      want_scores: bool = True, workspace: Optional[torch.Tensor] = None, images_in_flight: Optional[int] = None,
-                     profile=None, defer_status: bool = False, split=None, ws_slot: int = 0):
+                     profile=None, defer_status: bool = False):
         """tokens (the boundary's Q-side input) -> idx [B,k], values [B,k], scores [B,R] or None.
 
         defer_status (select path only): do NOT read the per-image status on the host here -- the call then enqueues work and
         nothing else (capturable in a hipGraph, no sync in the middle of a step) and leaves `self.pending_select`; the caller
-        reads the status together with its own results (one D2H per batch) and calls `finish_select` if any image was refused.
-
-        split (ops.SelectSplit, select path with defer_status only) + ws_slot (0 / 1): the tail of the batch -- everything behind the sweep -- runs on
-        split.tail_stream, in the module's select workspace number `ws_slot`; idx / val / status are then complete on THAT stream (6dgs_amd.test.PoseStream
-        alternates the two workspaces batch by batch and orders its readers).  `self.last_split` says whether the call took that form."""
+        reads the status together with its own results (one D2H per batch) and calls `finish_select` if any image was refused."""
         kc = self._ensure_keys(rays_ori, rays_dir, rays_rgb)
         w = self.packed_weights(rays_ori.device)
         q, n_tok, n_host = self._tokens_to_q(token_list, rays_ori.device)
         self.last_scoring_path = "two-pass"
         self.pending_select = None
-        self.last_split = False
         capturing = torch.cuda.is_current_stream_capturing()
         if (not want_scores and kc.get("sample") is not None and ops.select_enabled() and ops.effective_mma_mode() in ops.F16_MODES
                 and rays_to_output <= ops.SELECT_MAX_CANDIDATES and (defer_status or not capturing)):
@@ -262,21 +257,18 @@ class IdentificationModule(torch.nn.Module):
             # (status -1: too many near-ties for max_candidates, or an exponent overflow) go through the two-pass scorer below
             b, r = q.shape[0], rays_ori.shape[0]
             need = ops.score_select_workspace_bytes(r, b, rays_to_output, ops.SELECT_MAX_CANDIDATES)
-            slot_attr = "_select_ws_b" if (ws_slot == 1 and split is not None and defer_status) else "_select_ws"
-            sw = getattr(self, slot_attr, None)
+            sw = getattr(self, "_select_ws", None)
             if sw is None or sw.numel() < need or sw.device != q.device:
                 if capturing:
                     raise RuntimeError("6dgs_amd: the select workspace must exist before a hipGraph capture (run the batch once eagerly)")
-                setattr(self, slot_attr, None)
-                sw = ops.big_empty(need, torch.uint8, q.device)
-                setattr(self, slot_attr, sw)
-            self.last_split = split is not None and defer_status
+                self._select_ws = sw = None
+                self._select_ws = sw = ops.big_empty(need, torch.uint8, q.device)
             # Token packing (round 5): the library packs the images of a launch into the sweep's 256-token tiles by their token counts (two views of
             # <= 128 tokens or four of <= 64 share a tile; csrc/sweep_plan.h) -- masked views (Tanks&Temples / Blender keep 56-176 of 256 tokens) cost what
             # their tokens cost, in ONE call with nothing permuted on the host.  (Round 4 ran one full select pipeline per 64-token row-count class here.)
             idx, val, status = ops.score_select(q, n_tok, kc["planes"], kc["scale"], kc["sample"][0], kc["sample"][1], rays_to_output,
                                                 max_candidates=ops.SELECT_MAX_CANDIDATES, workspace=sw, profile=profile, n_tok_host=n_host,
-                                                key_norm=kc["norm"], split=split if self.last_split else None)
+                                                key_norm=kc["norm"])
             self.last_select_launches = ops.select_sweep_plan(n_host)          # [(tiles, images)] per sweep launch
             self.last_scoring_path = "select"
             pend = dict(status=status, q=q, n_tok=n_tok, k=rays_to_output, workspace=workspace, images_in_flight=images_in_flight,
@@ -290,19 +282,6 @@ class IdentificationModule(torch.nn.Module):
                                              images_in_flight=images_in_flight, profile=profile, n_tok_host=n_host,
                                              key_planes=kc["planes"], key_scale=kc["scale"])
         return idx, val, scores
-
-    def second_select_workspace_fits(self, batch: int, rays: int, device, k: int = 100) -> bool:
-        """Whether the select path can have TWO workspaces for batches of this size (20 B per ray and image each) -- what running the tail of a batch
-        beside the next batch's sweep takes (score_tokens(split=...)).  Scenes that nearly fill the GPU keep one workspace and one stream."""
-        need = ops.score_select_workspace_bytes(int(rays), int(batch), k, ops.SELECT_MAX_CANDIDATES)
-        have_b, have_a = getattr(self, "_select_ws_b", None), getattr(self, "_select_ws", None)
-        if have_b is not None and have_b.numel() >= need:
-            return True
-        want = need + (0 if (have_a is not None and have_a.numel() >= need) else need)
-        a = ops.get_arena()
-        if a is not None and need >= ops.ARENA_MIN_BYTES and a.buf.device == torch.device(device):
-            return a.capacity - a.mark() >= want + (64 << 20)
-        return ops._free_bytes(device) >= 1.15 * want + (2 << 30)
 
     @torch.no_grad()
     def finish_select(self, idx, val, pending=None, status_host=None):
@@ -397,7 +376,7 @@ class IdentificationModule(torch.nn.Module):
             if not (held is not None and held[0] == ident and all(h.data_ptr() == t.data_ptr() for h, t in zip(held[1], (rays_ori, rays_dir, rays_rgb)))):
                 self._stream_sample = held = None
                 if ops.get_arena() is not None:                  # a new scene: what the arena held for the previous one goes
-                    self._key_cache = self._key_cache_rays = self._select_ws = self._select_ws_b = None
+                    self._key_cache = self._key_cache_rays = self._select_ws = None
                     ops.get_arena().reset(self)
                 si = ops.select_sample_indices(r, dev)
                 _, _, (sp, sscale) = ops.ray_keys(rays_ori[si], rays_dir[si], rays_rgb[si], w, want_key=False, want_planes=True)

@@ -655,58 +655,11 @@ def select_sweep_plan(n_tok_host, batch: Optional[int] = None):
     return [(int(slots[i]), int(imgs[i])) for i in range(min(n, cap))]
 
 
-class SelectSplit:
-    """The second stream of a select batch (include/sixdgs.h: sixdgs_score_select_split): the sweep stays on the current stream, everything behind it --
-    merge of the token partials, U, candidates, re-score, top-k -- goes to `tail_stream` behind `done_event`.  wait_event: what the SWEEP (not the sample
-    pre-pass) waits for, normally the event behind the previous batch's tail.  xcd_cus: CUs per XCD of a CU-masked current stream (cu_masked_stream)."""
-
-    def __init__(self, tail_stream, wait_event=None, xcd_cus=None):
-        self.tail_stream, self.wait_event = tail_stream, wait_event
-        self.done_event = torch.cuda.Event()
-        self.done_event.record(tail_stream)                 # (a torch event gets its HIP handle on the first record)
-        self.xcd_cus = None if xcd_cus is None else [int(v) for v in xcd_cus]
-        if self.xcd_cus is not None and len(self.xcd_cus) != 8:
-            raise RuntimeError("6dgs_amd: xcd_cus holds the usable CUs of each of the 8 XCDs")
-
-
-N_XCD, CUS_PER_XCD = 8, 32             # MI355X: 256 CUs in 8 XCDs
-
-
-def cu_mask_words(xcd_cus, layout: str = "xcd-minor"):
-    """CU-mask words for hipExtStreamCreateWithCUMask that leave xcd_cus[x] CUs of XCD x usable (the LAST CUs of an XCD are the ones taken away).
-    layout "xcd-minor": mask bit i is CU i // 8 of XCD i % 8 (how the kernel driver distributes the mask over the XCCs of one device, measured by
-    tools/probe_cumask.py); "xcd-major": bit i is CU i % 32 of XCD i // 32."""
-    bits = 0
-    for x in range(N_XCD):
-        for c in range(int(xcd_cus[x])):
-            bits |= 1 << ((c * N_XCD + x) if layout == "xcd-minor" else (x * CUS_PER_XCD + c))
-    return [(bits >> (32 * i)) & 0xFFFFFFFF for i in range(N_XCD * CUS_PER_XCD // 32)]
-
-
-def cu_masked_stream(device, mask_words):
-    """A torch stream restricted to the CUs of the mask (sixdgs_stream_create_cu_mask).  The HIP stream lives as long as the process (a handful per process)."""
-    lib = _lib.load()
-    with torch.cuda.device(device):
-        arr = (C.c_uint32 * len(mask_words))(*[int(w) for w in mask_words])
-        out = C.c_void_p()
-        check(lib.sixdgs_stream_create_cu_mask(arr, len(mask_words), C.byref(out)), "stream_create_cu_mask")
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
-@_on_device
-def wg_placement(n_wgs: int, spin_cycles: int = 2_000_000):
-    """(xcc id, HW_ID & 0xff00 = se / sh / cu) of every workgroup of a one-per-CU launch on the current stream (tools/probe_cumask.py)."""
-    out = torch.zeros(n_wgs, dtype=torch.int32, device="cuda")
-    check(_lib.load().sixdgs_debug_wg_placement(int(n_wgs), int(spin_cycles), _p(out), _stream()), "debug_wg_placement")
-    v = out.cpu().numpy().astype("int64") & 0xFFFFFFFF
-    return (v >> 16) & 0xF, v & 0xFF00
-
-
 @_on_device
 def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor, key_scale: torch.Tensor, sample_planes: torch.Tensor,
                  sample_scale: torch.Tensor, topk: int = 100, max_candidates: int = SELECT_MAX_CANDIDATES,
                  workspace: Optional[torch.Tensor] = None, profile: Optional["KernelProfile"] = None, n_tok_host=None,
-                 key_norm: Optional[torch.Tensor] = None, split: Optional[SelectSplit] = None):
+                 key_norm: Optional[torch.Tensor] = None):
     """Top-k without materialised logits (include/sixdgs.h: sixdgs_score_select).  Returns (idx [B,k], val [B,k], status [B] int32 on
     the device: candidates examined, or -1 = this image needs the two-pass scorer).  key_norm: key_norm_max(key_planes, key_scale),
     computed here (one more pass over the planes) when not handed in -- callers with a key cache keep it beside the planes.
@@ -726,15 +679,6 @@ def score_select(q: torch.Tensor, n_tok: torch.Tensor, key_planes: torch.Tensor,
         workspace = torch.empty(score_select_workspace_bytes(r, b, topk, max_candidates), dtype=torch.uint8, device=dev)
     # the host copy of the token counts: with it the sweep PACKS the images of a launch by their token counts (round 5; include/sixdgs.h)
     h_n = (C.c_int32 * b)(*[int(v) for v in n_tok_host]) if n_tok_host is not None else None
-    if split is not None:
-        # the tail of the batch on split.tail_stream: idx / val / status are complete THERE (the caller orders its readers behind that stream)
-        xc = (C.c_uint8 * 8)(*split.xcd_cus) if split.xcd_cus is not None else None
-        check(lib.sixdgs_score_select_split(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), _p(key_norm), r, _p(sample_planes), _p(sample_scale), rs,
-                                            int(topk), int(max_candidates), _p(idx), _p(val), _p(status), _p(workspace), workspace.numel(), _stream(),
-                                            C.c_void_p(split.tail_stream.cuda_stream), C.c_void_p(split.done_event.cuda_event),
-                                            C.c_void_p(split.wait_event.cuda_event) if split.wait_event is not None else None, xc,
-                                            profile.ref if profile is not None else None), "score_select_split")
-        return idx, val, status
     check(lib.sixdgs_score_select(_p(q), _p(n_tok), h_n, b, _p(key_planes), _p(key_scale), _p(key_norm), r, _p(sample_planes), _p(sample_scale), rs,
                                   int(topk), int(max_candidates), _p(idx), _p(val), _p(status), _p(workspace), workspace.numel(), _stream(),
                                   profile.ref if profile is not None else None), "score_select")

@@ -222,23 +222,6 @@ def resolve_poses(id_module, sol, packed_host):
     return again["c2w"].cpu()
 
 
-def _sweep_cu_config():
-    """SIXDGS_SWEEP_CU_MASK: CUs taken away from the sweep's stream and given to the image + tail streams, as "<n>" (n CUs of XCD 7) or "<n>x<m>" (n CUs
-    of each of the last m XCDs; "4x8" = 4 CUs of every XCD); unset / 0: no mask.  -> (xcd_cus [8] | None, sweep mask words | None, complement words | None)."""
-    from . import ops as _ops
-    v = os.environ.get("SIXDGS_SWEEP_CU_MASK", "").strip().lower()
-    if not v or v == "0":
-        return None, None, None
-    n, m = (v.split("x") + ["1"])[:2]
-    n, m = int(n), int(m)
-    if not (1 <= m <= _ops.N_XCD and 1 <= n < _ops.CUS_PER_XCD):
-        raise RuntimeError(f"6dgs_amd: SIXDGS_SWEEP_CU_MASK={v}: need 1 <= CUs < {_ops.CUS_PER_XCD} of 1..{_ops.N_XCD} XCDs")
-    xc = [_ops.CUS_PER_XCD] * (_ops.N_XCD - m) + [_ops.CUS_PER_XCD - n] * m
-    layout = os.environ.get("SIXDGS_CU_MASK_LAYOUT", "xcd-minor")
-    words = _ops.cu_mask_words(xc, layout)
-    return xc, words, [(~w) & 0xFFFFFFFF for w in words]
-
-
 class PoseStream:
     """Batches of query images through `estimate_poses` as a PIPELINE: the reference's evaluation is exactly such a stream of views
     (pose_estimation/test.py:46-302), and poses/s over a test set is what the metric counts.
@@ -247,53 +230,33 @@ class PoseStream:
       c2w, sol = ps.collect(handle)       # later: the batch's poses on the host
 
     With one batch submitted before the previous one is collected, (a) the host never sits between the GPU's last kernel of batch N and its
-    first of batch N + 1, and (b) the image side -- ~250 small kernels, ViT-S/14 + camera-up CNN -- runs on its OWN stream.
-    Round 6: the image side runs ONE BATCH FURTHER AHEAD than the scorer ("lead").  submit(N) enqueues the image side of batch N at once but the scoring of
-    batch N only when the next submit (or its collect) comes; in the loop `submit(N + 1); collect(N)` the ViT of N + 1 therefore has the whole of sweep N
-    and both windows around it to finish in, and `q_proj` of a batch never waits for its tokens.  Before, the ViT of N + 1 was enqueued together with the
-    scoring of N + 1: it had only the ~2 ms between two sweeps (a sweep holds every CU: 2 waves x 256 registers per SIMD, 160 KB of LDS), did not fit
-    (ViT ~ 2.0 ms against a 1.3 ms tail), and what was left of it sat on the critical path in front of the next pre-pass.  SIXDGS_POSE_STREAM_LEAD=0 undoes it.
+    first of batch N + 1 (round 4: every step ended in a device sync before the next image side was even enqueued), and (b) the image side of
+    batch N + 1 -- ~250 small kernels, ViT-S/14 + camera-up CNN -- runs on its OWN stream, so it fills the compute units the sweep of batch N
+    frees in its tail and overlaps batch N's small serial kernels (finish of U, selections, re-score, pose solve, D2H).  The scorer itself
+    stays in order on the caller's stream (one sweep holds every CU: its registers and LDS leave room for nothing else).
     Poses are bit-identical to the unpipelined run: the same kernels on the same data in the same order per batch.
-
-    Opt-in (measured in round 6, `profiles/r06_pipeline_ab.md`; neither is faster than the default, both stay tested):
-      SIXDGS_POSE_STREAM_TAIL=1   a third stream for everything BEHIND the sweep of a batch (merge of the token partials, U, thresholds, candidates, exact
-                                  re-score, top-k, pose solve, D2H) beside the next batch's pre-pass, two select workspaces (sixdgs_score_select_split);
-      SIXDGS_SWEEP_CU_MASK=<n>x<m> (with the tail stream) the sweep on a CU-masked stream that leaves n CUs of the last m XCDs to the image and tail streams,
-                                  which are confined to exactly those (SIXDGS_SIDE_STREAMS_UNMASKED=1: not confined).
+    Round 6 built and measured three further arrangements -- the tail of a batch on a third stream, the sweep on a CU-masked stream with the image and
+    tail streams on the CUs it leaves out, the image side one batch further ahead -- none faster than this one (profiles/r06_pipeline_ab.md; commit b2320e2).
 
     Inputs of batch N must exist before submit(N - 1) was called, or be produced on `ps.image_stream` (uploads under
-    `with torch.cuda.stream(ps.image_stream)`): the image stream does not wait for the caller's stream beyond that point."""
+    `with torch.cuda.stream(ps.image_stream)`): the image stream does not wait for the caller's stream beyond that point.
+    The image-side hipGraphs and their static token / camera-up buffers are the MODULE's (one capture per batch shape serves every scene of a sweep): the first
+    submit waits for the caller's stream, so a PoseStream may follow `estimate_poses` calls on the same module; do not call `estimate_poses(image_graph=True)`
+    BETWEEN the submits of a PoseStream without a host sync in between -- its replay would rewrite buffers the other stream may still read."""
 
     def __init__(self, id_module, rays_ori, rays_dirs, rays_rgb, k: int = 100, workspace=None, images_in_flight=None):
         self.idm, self.rays, self.k = id_module, (rays_ori, rays_dirs, rays_rgb), k
         self.workspace, self.images_in_flight = workspace, images_in_flight
-        dev = rays_ori.device
-        self._fence = None            # recorded on the sweep stream at the START of the previous submit
-        self.lead = os.environ.get("SIXDGS_POSE_STREAM_LEAD", "1") != "0"
-        self.use_tail = os.environ.get("SIXDGS_POSE_STREAM_TAIL", "0") == "1"
-        self.xcd_cus, words, rest = _sweep_cu_config() if self.use_tail else (None, None, None)
-        self.sweep_stream = ops.cu_masked_stream(dev, words) if words is not None else None
-        # with a CU-masked sweep the image and tail streams are confined to the CUs it leaves out (SIXDGS_SIDE_STREAMS_UNMASKED=1: anywhere): unconfined,
-        # their small workgroups keep landing on the sweep's CUs, and a persistent sweep workgroup needs its CU EMPTY
-        confined = rest is not None and os.environ.get("SIXDGS_SIDE_STREAMS_UNMASKED") != "1"
-        self.image_stream = ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)
-        self.tail_stream = (ops.cu_masked_stream(dev, rest) if confined else torch.cuda.Stream(device=dev)) if self.use_tail else None
-        self._split_ok = None         # decided at the first scoring: is there room for the second select workspace?
-        self._tail_done = [None, None]        # event behind the tail that last used select workspace 0 / 1
-        self._n = 0                   # batches scored so far
-        self._waiting = None          # the handle whose image side is enqueued and whose scoring is not (lead)
+        self.image_stream = torch.cuda.Stream(device=rays_ori.device)
+        self._fence = None            # recorded on the caller's stream at the START of the previous submit
 
     @torch.no_grad()
     def submit(self, images, gt_c2w=None, profile=None, tokens=None, up=None):
-        caller = torch.cuda.current_stream()
-        main = self.sweep_stream if self.sweep_stream is not None else caller
+        main = torch.cuda.current_stream()
         side = self.image_stream
-        if main is not caller and self._n == 0 and self._waiting is None:
-            main.wait_stream(caller)             # the scene's key planes, weights and rays were produced on the caller's stream
-        handle = {"sol": None, "host": None, "done": None, "gt": gt_c2w, "profile": profile, "ready": None, "up_ready": None}
         if tokens is None:
             if self._fence is None:
-                side.wait_stream(caller)
+                side.wait_stream(main)
             else:
                 side.wait_event(self._fence)
             fence = torch.cuda.Event()
@@ -305,91 +268,43 @@ class PoseStream:
                 if res is not None:
                     # the graphs' outputs are STATIC buffers, rewritten by the next replay: this batch keeps its own copies (1.6 MB at 4 images).
                     # The tokens are ready when the ViT graph is; the camera-up CNN (needed only by the pose solve at the END of the batch) is replayed
-                    # behind them and does not sit on the path to the sweep
+                    # behind them and no longer sits on the path to the sweep
                     tk = res[0]
                     tokens = type(tk)(tk.feats.clone(), tk.pe) if hasattr(tk, "feats") else tk.clone()
-                    handle["ready"] = torch.cuda.Event()
-                    handle["ready"].record(side)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
                     up = cache.cnn().clone()
-                    handle["up_ready"] = torch.cuda.Event()
-                    handle["up_ready"].record(side)
+                    up_ready = torch.cuda.Event()
+                    up_ready.record(side)
                 else:
                     imgs_f, masks = prepare_images_device(images)
                     tokens, fmaps = self.idm.image_tokens(imgs_f, masks)
                     up = self.idm.camera_up(fmaps)
-                    handle["ready"] = handle["up_ready"] = torch.cuda.Event()
-                    handle["ready"].record(side)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    up_ready = ready
+            main.wait_event(ready)
+            for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))) + [up]:
+                t.record_stream(main)          # allocated on the image stream, read on the caller's
         else:
-            handle["injected"] = torch.cuda.Event()     # injected tokens / camera-up vectors come from the caller's stream
-            handle["injected"].record(caller)
-        handle["tokens"], handle["up"] = tokens, up
-        prev, self._waiting = self._waiting, handle
-        if prev is not None:
-            self._score(prev)
-        if not self.lead:
-            self._score(handle)
-            self._waiting = None
-        return handle
-
-    def _score(self, handle):
-        """Second half of a batch: q_proj, sample pre-pass, sweep, tail, pose solve, the batch's one D2H -- everything behind the tokens."""
-        caller = torch.cuda.current_stream()
-        main = self.sweep_stream if self.sweep_stream is not None else caller
-        side = self.image_stream
-        tokens, up, gt_c2w = handle["tokens"], handle["up"], handle["gt"]
-        if handle["ready"] is not None:
-            main.wait_event(handle["ready"])
-            for t in ([tokens.feats] if hasattr(tokens, "feats") else ([tokens] if torch.is_tensor(tokens) else list(tokens))):
-                t.record_stream(main)          # allocated on the image stream, read on the sweep's
-        elif main is not caller:
-            main.wait_event(handle["injected"])
-        b = len(tokens) if not torch.is_tensor(tokens) else tokens.shape[0]
-        if self._split_ok is None:
-            self._split_ok = bool(self.use_tail and self.idm.second_select_workspace_fits(b, self.rays[0].shape[0], self.rays[0].device, self.k))
-        slot = self._n & 1
-        self._n += 1
-        split = None
-        if self._split_ok:
-            if self._tail_done[slot] is not None:
-                main.wait_event(self._tail_done[slot])          # workspace `slot` is free again once the tail that read it last has retired
-            # without a CU mask the sweep waits for the PREVIOUS batch's tail: a persistent sweep leaves that tail no CU to finish on
-            split = ops.SelectSplit(self.tail_stream, wait_event=self._tail_done[slot ^ 1] if self.sweep_stream is None else None, xcd_cus=self.xcd_cus)
-        with torch.cuda.stream(main):
-            idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
-                                                         images_in_flight=self.images_in_flight, profile=handle["profile"], defer_status=True, split=split,
-                                                         ws_slot=slot)
-        tail = self.tail_stream if self._split_ok else main
-        if tail is not main:
-            tail.wait_stream(main)             # (the two-pass fallback of a whole batch leaves its results on the sweep's stream)
-            pend = getattr(self.idm, "pending_select", None)
-            for t in [idx, weights] + ([pend["status"], pend["q"], pend["n_tok"]] if pend is not None else []):
-                t.record_stream(tail)          # allocated on the sweep's stream, read by the tail
-        with torch.cuda.stream(tail):
-            if handle["up_ready"] is not None:
-                tail.wait_event(handle["up_ready"])
-            if tail is not side and up is not None and handle["up_ready"] is not None:
-                up.record_stream(tail)
-            if gt_c2w is not None and tail is not caller:
-                gt_c2w.record_stream(tail)
-            sol = _solve_batch(self.idm, idx, weights, scores, tokens, up, self.rays[0], self.rays[1], gt_c2w, True)
-            # the batch's ONE D2H, behind an event instead of a device sync: [c2w (16) | select status | solve status | t err | ang err | mean kept weight | kept]
-            full = torch.cat([sol["packed"], sol["status"].to(torch.float32)[:, None], sol["errors"].to(torch.float32),
-                              (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1))[:, None], sol["n_kept"].to(torch.float32)[:, None]], dim=1)
-            host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
-            host.copy_(full, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(tail)
-        if self._split_ok:
-            self._tail_done[slot] = done
-        handle.update(sol=sol, host=host, done=done, keep=full)
+            up_ready = None
+        idx, weights, scores = self.idm.score_tokens(tokens, *self.rays, self.k, want_scores=False, workspace=self.workspace,
+                                                     images_in_flight=self.images_in_flight, profile=profile, defer_status=True)
+        if up_ready is not None:
+            main.wait_event(up_ready)
+        sol = _solve_batch(self.idm, idx, weights, scores, tokens, up, self.rays[0], self.rays[1], gt_c2w, True)
+        # the batch's ONE D2H, behind an event instead of a device sync: [c2w (16) | select status | solve status | t err | ang err | mean kept weight | kept]
+        full = torch.cat([sol["packed"], sol["status"].to(torch.float32)[:, None], sol["errors"].to(torch.float32),
+                          (sol["w_final"].sum(dim=1) / sol["n_kept"].clamp(min=1))[:, None], sol["n_kept"].to(torch.float32)[:, None]], dim=1)
+        host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
+        host.copy_(full, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(main)
+        return {"sol": sol, "host": host, "done": done}
 
     @torch.no_grad()
     def collect(self, handle):
         """-> (c2w [B,4,4] on the host, sol).  Images the select path refused are re-done here by the two-pass scorer (rare)."""
-        if handle["done"] is None:             # its scoring has not been enqueued yet (no later submit came): now
-            if self._waiting is handle:
-                self._waiting = None
-            self._score(handle)
         handle["done"].synchronize()
         return resolve_poses(self.idm, handle["sol"], handle["host"][:, :17]), handle["sol"]
 

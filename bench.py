@@ -460,12 +460,8 @@ def main():
                          + "; backbone ViT-S/14 + camera-up CNN random-init on PyTorch-ROCm"),
             "preset": args.config, "mode": args.mode, "gaussians": args.gaussians, "rays": R_total, "images_per_gpu_per_step": args.batch,
             "scoring": args.scoring, "images_per_logits_launch": inflight, "hip_graph": bool(args.graph),
-            "pipeline": (("2 batches in flight (6dgs_amd.test.PoseStream): batch N + 1 submitted before batch N's poses are collected; image side on its own stream; "
-                          + ("the tail of a batch (U, candidates, re-score, top-k, pose solve, D2H) on a third stream beside the next batch's pre-pass"
-                             + (f" and sweep (sweep stream CU-masked: {ps_main.xcd_cus} CUs per XCD)" if ps_main.sweep_stream is not None else
-                                " (the next sweep waits for it: no CU mask)") + ", two select workspaces"
-                             if ps_main._split_ok else "scorer and its tail in order on one stream")
-                          + "; one D2H per batch behind an event; --no-pipeline = one batch at a time") if pipelined
+            "pipeline": ("2 batches in flight (6dgs_amd.test.PoseStream): batch N + 1 submitted before batch N's poses are collected, its image side on a second "
+                         "stream; scorer in order on one stream; one D2H per batch behind an event; --no-pipeline = one batch at a time" if pipelined
                          else "none: one batch at a time, a device sync per step"),
             # select path: how the library cut this batch into sweep launches -- (256-token tiles, images) per launch, from the library's own planner with
             # the token counts of the last batch (csrc/sweep_plan.h: launches of 8 tiles, images packed into tiles by token count; SIXDGS_SWEEP_MAX_IMAGES)
@@ -517,7 +513,7 @@ def main():
                               "sweep_tflops": round(f8 / (m8 * 1e-3) / 1e12, 2) if m8 > 0 else None,
                               "note": "the headline workload at 8 images per GPU and step (one sweep launch of 8 tiles), same pipeline; `value` above stays the 4-image figure of rounds 1-5"}
         del ps8, images8, gts8
-        idm._select_ws = idm._select_ws_b = None
+        idm._select_ws = None
     if l24 is not None:
         out["two_pass_mode"] = l24
     if l32 is not None:

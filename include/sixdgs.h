@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_score_select_split (the tail of a select batch on a second stream, CU-masked sweep streams), the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 6   /* 6: the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -348,31 +348,6 @@ int sixdgs_score_select(const float* q, const int32_t* d_n_tok, const int32_t* h
                         const void* sample_planes, const float* d_sample_scale, int64_t r_sample, int topk, int max_candidates, int64_t* idx /*[B,topk]*/,
                         float* val /*[B,topk]*/, int32_t* d_status /*[B]*/, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
                         sixdgs_profile* prof);
-/* sixdgs_score_select with the TAIL of the batch on a second stream (round 6).  The reference's evaluation is a stream of views (test.py:46-302); behind
- * the matrix-core sweep of a batch come ~20 small launches (merge of the token partials, U = sum of the quarter rows, thresholds, candidate compaction,
- * exact re-score, top-k) that occupy a handful of CUs for ~1.3 ms -- in one stream they hold back the next batch's pre-pass and sweep.  Here:
- *   `stream`       sample pre-pass, q planes, the sweep launches;
- *   `tail_stream`  everything behind a sweep launch, after `sweep_done_event` (a hipEvent_t of the caller, recorded on `stream` behind every sweep launch);
- *                  idx / val / d_status are complete on THIS stream.  NULL or == stream: exactly sixdgs_score_select;
- *   `sweep_wait_event`  (hipEvent_t or NULL) the first sweep launch -- not the pre-pass before it -- waits for it: a caller without a CU-masked sweep stream
- *                  passes the event behind the PREVIOUS batch's tail, so that a persistent sweep never starts while that tail still needs a CU;
- *   `h_sweep_xcd_cus`   (host, 8 entries, or NULL) CUs of each XCD that `stream` may use when it was created with a CU mask
- *                  (hipExtStreamCreateWithCUMask): the persistent sibling sets of the sweep are laid out on exactly those, whole sets per XCD, and the
- *                  CUs left out serve the tail and image streams WHILE a sweep runs.
- * The caller alternates between TWO workspaces batch by batch (the tail of batch N reads its workspace while batch N + 1 sweeps) and does not reuse a
- * workspace before the tail that read it last has finished.  The whole batch must fit the workspace in one group (SIXDGS_E_WORKSPACE otherwise).
- * Same results, bit for bit, as sixdgs_score_select. */
-int sixdgs_score_select_split(const float* q, const int32_t* d_n_tok, const int32_t* h_n_tok, int batch, const void* key_planes, const float* d_key_scale,
-                              const float* d_key_norm_max, int64_t r, const void* sample_planes, const float* d_sample_scale, int64_t r_sample, int topk,
-                              int max_candidates, int64_t* idx, float* val, int32_t* d_status, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
-                              sixdgs_stream_t tail_stream, void* sweep_done_event, void* sweep_wait_event, const uint8_t* h_sweep_xcd_cus,
-                              sixdgs_profile* prof);
-/* A stream that may use only the CUs whose bit is set in h_mask (hipExtStreamCreateWithCUMask; `words` 32-bit words) -- for the sweep of
- * sixdgs_score_select_split -- and its release.  sixdgs_debug_wg_placement: out[i] = (XCC id << 16) | HW_ID[15:0] of workgroup i of a launch of
- * one-per-CU workgroups on `stream` (which mask bit is which CU: tools/probe_cumask.py). */
-int sixdgs_stream_create_cu_mask(const uint32_t* h_mask, int words, sixdgs_stream_t* out);
-int sixdgs_stream_destroy(sixdgs_stream_t stream);
-int sixdgs_debug_wg_placement(int n_wgs, int64_t spin_cycles, uint32_t* d_out, sixdgs_stream_t stream);
 /* top-k alone over precomputed scores [B,R] */
 size_t sixdgs_topk_workspace_bytes(int64_t r, int batch, int topk);
 int sixdgs_topk(const float* scores, int64_t r, int batch, int topk, int64_t* idx, float* val, void* ws,

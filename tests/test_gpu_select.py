@@ -519,49 +519,3 @@ def test_streamed_scene_with_an_arena_survives_a_refused_image(ops, syn):
         ops.SELECT_MAX_CANDIDATES = old
         ops.set_arena(prev)
         idm.invalidate_caches()
-
-
-def test_tail_on_a_second_stream_is_invisible(ops):
-    """Round 6 (sixdgs_score_select_split): the tail of a select batch -- merge of the token partials, U, candidates, re-score, top-k -- on a second
-    stream, the launches of the batch in disjoint slot ranges of the workspace.  20 views with mixed token counts (three sweep launches: 8 + 8 + 4 tiles
-    worth of quarters), (a) split with a plain tail stream, (b) the sweep on a CU-MASKED stream (4 CUs of XCD 7 left out: whole sibling sets per XCD on the
-    CUs it may use) with a wait event in front of the sweep, (c) the same batch twice in a row on alternating workspaces while the first tail may still run.
-    Every variant returns the same rays, values and statuses as sixdgs_score_select, bit for bit."""
-    n_tok = (256, 40, 64, 65, 128, 200, 0, 256, 137, 256, 256, 31, 256, 192, 256, 100, 256, 256, 7, 256)
-    c = make_case(ops, 1_100_037, 57, 6.0, n_tok)
-    assert len(ops.select_sweep_plan(list(n_tok))) >= 2
-    norm = ops.key_norm_max(c["planes"], c["scale"])
-    args = (c["q"], c["nt"], c["planes"], c["scale"], c["s_planes"], c["s_scale"], 100)
-    ref = ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm)
-    need = ops.score_select_workspace_bytes(1_100_037, len(n_tok), 100, ops.SELECT_MAX_CANDIDATES)
-    ws = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    cur, tail = torch.cuda.current_stream(), torch.cuda.Stream()
-    # (a)
-    out = ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm, workspace=ws[0], split=ops.SelectSplit(tail))
-    tail.synchronize()
-    for a, b in zip(out, ref):
-        assert torch.equal(a, b)
-    # (c) two batches back to back, workspaces alternating, the second sweep waiting for the first tail (what PoseStream does without a CU mask)
-    ev = torch.cuda.Event()
-    o1 = ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm, workspace=ws[0], split=ops.SelectSplit(tail))
-    ev.record(tail)
-    o2 = ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm, workspace=ws[1], split=ops.SelectSplit(tail, wait_event=ev))
-    tail.synchronize()
-    for o in (o1, o2):
-        for a, b in zip(o, ref):
-            assert torch.equal(a, b)
-    # (b) CU-masked sweep stream
-    xc = [32] * 7 + [28]
-    masked = ops.cu_masked_stream("cuda:0", ops.cu_mask_words(xc))
-    masked.wait_stream(cur)
-    with torch.cuda.stream(masked):
-        o3 = ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm, workspace=ws[0], split=ops.SelectSplit(tail, xcd_cus=xc))
-    tail.synchronize()
-    masked.synchronize()
-    for a, b in zip(o3, ref):
-        assert torch.equal(a, b)
-    # a batch that does not fit the workspace in ONE group is refused in split mode (a second group would reuse the fields under the first one's tail)
-    small = torch.empty(ops.score_select_workspace_bytes(1_100_037, 10, 100, ops.SELECT_MAX_CANDIDATES), dtype=torch.uint8, device="cuda")
-    with pytest.raises(RuntimeError, match="workspace"):
-        ops.score_select(*args, n_tok_host=list(n_tok), key_norm=norm, workspace=small, split=ops.SelectSplit(tail))
-    torch.cuda.synchronize()
