@@ -147,10 +147,79 @@ class ViTS14(torch.nn.Module):
         b = x.shape[0]
         t = self.patch_embed(x)
         t = torch.cat([self.cls_token.expand(b, -1, -1), t], dim=1) + self._pos(x.shape[-1] // self.patch_size)
-        for blk in self.blocks:
-            t = blk(t)
+        if fused_blocks_usable(self, t):
+            t = fused_blocks(self.blocks, t)
+        else:
+            for blk in self.blocks:
+                t = blk(t)
         t = self.norm(t)
         return {"x_norm_clstoken": t[:, 0], "x_norm_patchtokens": t[:, 1:]}
+
+
+# ---- the transformer blocks at inference on the GPU: five launches per block (round 6) -------------------------------------------------------------
+# From how many token rows (257 x images) each dense stage of a block runs through sixdgs_tok_linear instead of PyTorch's kernels: GPU time per stage
+# inside a hipGraph on MI355X, profiles/r06_vit_stages.md.  Below ~8 images the library's launch-bound 8 us GEMMs win on the two N = 384 products
+# (proj, FC2: a 64-token tile gives them 10 .. 30 workgroups), while the two LayerNorm-fused ones win from 2 images (LN + FC1 + GELU always).
+FUSED_MIN_ROWS = {"qkv": 2 * 257, "proj": 8 * 257, "fc1": 0, "fc2": 16 * 257}
+
+
+def fused_blocks_usable(vit, t) -> bool:
+    """The fused form serves fp32 inference on the GPU of blocks with the ViT-S layout (width 384 = 6 heads of 64, dinov2's parameter names);
+    SIXDGS_VIT_FUSED=0 keeps PyTorch's kernels (the comparison the tests make), =all sends every stage through sixdgs_tok_linear whatever the batch."""
+    if not t.is_cuda or torch.is_grad_enabled() or t.dtype != torch.float32 or os.environ.get("SIXDGS_VIT_FUSED", "1") == "0":
+        return False
+    try:
+        blk = vit.blocks[0]
+        return (t.shape[-1] == 384 and blk.attn.num_heads * 64 == 384 and tuple(blk.attn.qkv.weight.shape) == (1152, 384)
+                and blk.mlp.fc1.weight.shape[1] == 384 and blk.mlp.fc2.weight.shape[0] == 384 and blk.attn.qkv.bias is not None)
+    except AttributeError:
+        return False
+
+
+def fused_blocks(blocks, t: torch.Tensor) -> torch.Tensor:
+    """x + ls1(attn(norm1(x))), then x + ls2(mlp(norm2(x))) for every block (_Block.forward; dinov2's NestedTensorBlock at inference) as FIVE launches:
+         LayerNorm + QKV product + bias                              (sixdgs_tok_linear: A_LAYERNORM, EPI_BIAS)
+         attention on strided views of that [M, 1152] matrix         (F.scaled_dot_product_attention; its output is token-major: no copies either side)
+         proj + bias, LayerScale, residual                           (A_PLAIN, EPI_RESID, in place on the residual stream)
+         LayerNorm + FC1 + bias + GELU                               (A_LAYERNORM, EPI_GELU)
+         FC2 + bias, LayerScale, residual                            (A_PLAIN, EPI_RESID, in place)
+    instead of twelve (2 LayerNorm, 4 GEMM, attention, GELU, 2 addcmul, 2 layout copies); a stage whose token matrix is below its row count in
+    FUSED_MIN_ROWS keeps PyTorch's kernels.  The weights are split into fp16 planes once (ops.TokWeights, re-packed when a parameter changes); fp32-class
+    results (two planes x three terms, fp32 accumulation)."""
+    from . import ops
+    b, n, c = t.shape
+    m = b * n
+    force = os.environ.get("SIXDGS_VIT_FUSED", "1") == "all"
+    own = {k: force or m >= v for k, v in FUSED_MIN_ROWS.items()}
+    x = t.reshape(m, c).contiguous()
+    if x.data_ptr() == t.data_ptr():
+        x = x.clone()          # the residual stream is updated in place: never the caller's tensor
+    one = None
+    for blk in blocks:
+        h = blk.attn.num_heads
+        g1 = blk.ls1.gamma if hasattr(blk, "ls1") and hasattr(blk.ls1, "gamma") else None
+        g2 = blk.ls2.gamma if hasattr(blk, "ls2") and hasattr(blk.ls2, "gamma") else None
+        if (g1 is None or g2 is None) and one is None:
+            one = torch.ones(c, device=x.device)
+        if own["qkv"]:
+            qkv = ops.tok_linear(x, blk.attn.qkv.weight, blk.attn.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
+        else:
+            qkv = blk.attn.qkv(blk.norm1(x))
+        q, k, v = qkv.view(b, n, 3, h, c // h).permute(2, 0, 3, 1, 4).unbind(0)
+        y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(m, c)
+        if own["proj"]:
+            ops.tok_linear(y, blk.attn.proj.weight, blk.attn.proj.bias, epilogue=ops.TOK_EPI_RESID, residual=x, gamma=g1, out=x)
+        else:
+            x = torch.addcmul(x, blk.attn.proj(y), g1 if g1 is not None else one)
+        if own["fc1"]:
+            hid = ops.tok_linear(x, blk.mlp.fc1.weight, blk.mlp.fc1.bias, ln=(blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), epilogue=ops.TOK_EPI_GELU)
+        else:
+            hid = F.gelu(blk.mlp.fc1(blk.norm2(x)))
+        if own["fc2"]:
+            ops.tok_linear(hid, blk.mlp.fc2.weight, blk.mlp.fc2.bias, epilogue=ops.TOK_EPI_RESID, residual=x, gamma=g2, out=x)
+        else:
+            x = torch.addcmul(x, blk.mlp.fc2(hid), g2 if g2 is not None else one)
+    return x.view(b, n, c)
 
 
 def create_backbone(type="dino", backbone: Optional[torch.nn.Module] = None, **kwargs):

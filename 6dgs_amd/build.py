@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "lib6dgs_hip.so")
 HOSTCHECK = os.path.join(CSRC, "libsixdgs_hostcheck.so")
-SOURCES = ["geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip"]
+SOURCES = ["geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip", "vit.hip"]
 HEADERS = ["common.h", "device_math.h", "gemm_kernel.h", "dense.h", os.path.join("..", "..", "include", "sixdgs.h"), "dense_layout.h", "sweep_plan.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

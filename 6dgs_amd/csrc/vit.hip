@@ -1,0 +1,401 @@
+// vit.hip -- the dense products of the image side (the backbone stage; pose_estimation/backbone.py:82-114 runs DINOv2 ViT-S/14 on every
+// query image) with the neighbouring elementwise work folded in: LayerNorm in front of a product, bias / GELU / residual + LayerScale behind it.  A ViT
+// block is five launches (LN1+QKV, attention, proj+residual, LN2+FC1+GELU, FC2+residual) instead of twelve.
+//
+// Why a second GEMM kernel: the token matrix of a batch is M = 257 x images rows (257 .. 4112 for 1 .. 16 images) by K = 384 or 1536.  The 128 x 128 tile
+// of gemm.hip leaves most compute units without a workgroup at these sizes and splits BOTH operands in its main loop; the library's fp32-MFMA kernels run
+// the four products of a block at 60 .. 115 TFLOP/s at 16 images and at ~8 us each (launch-bound) at one (profiles/r06_vit_stages.md).
+//
+// Shape of k_tok_gemm (round 6, fourth form; what the first three lost to is in profiles/r06_vit_stages.md):
+//   * WEIGHTS are constants: split ONCE (sixdgs_tok_pack) into two scaled fp16 planes, one power-of-two scale per row, and stored in the MFMA's own
+//     operand order -- [32-feature block][k-slab][plane][k-step][lane][16 B] -- so that a wave's fragment load is 1 KB of consecutive bytes straight
+//     from L2 into registers: no LDS, no barrier and no split work for the weight operand, PFW slabs in flight per wave, loads unconditional (a cursor
+//     that stops on the last set) so that the compiler counts them (a load under a branch made it drain the queue every ring revolution).
+//   * TOKENS (the activation rows) are staged once per workgroup: a tile of 64 token rows x 384 columns is read as fp32 (16 lanes per row: the row's
+//     LayerNorm statistics and its largest magnitude are DPP butterflies over registers the wave holds anyway), normalised if asked, scaled by the
+//     row's power of two, split into two fp16 planes and left in LDS (110 KB) for the whole contraction.  K = 1536 (FC2) = four such chunks, each with
+//     its own row scale, accumulated in fp32.
+//   * a wave owns 32 features x 64 tokens (two 32 x 32 accumulators); a workgroup is EIGHT waves = 256 features x 64 tokens, two waves per SIMD: with
+//     four (one per SIMD) every latency of the staging, of the fragment reads and of the epilogue stood exposed (cycle stamps: 3.4 us of matrix work in
+//     a 9 us tile).  A workgroup walks over several feature tiles of its token tile when there are more tiles than compute units.
+//   * the epilogue's per-feature constants are requested before the slab loop, the residual rows all at once behind it; the GELU's erf is a rational
+//     form good to 1.5e-7 (12 VALU operations instead of libm's ~40: the erf was 2 us of a 5 us epilogue).
+//   * arithmetic as everywhere in this library: x 2^s = h + l, three cross terms l*h + h*l + h*h on v_mfma_f32_32x32x16_f16, fp32 accumulation.
+// Orientation: C[feature][token] (weights = MFMA rows): a lane owns ONE token per accumulator and 4 consecutive features per register group, so the
+// token's scale is one factor per lane and the epilogue writes 16-byte pieces of a token's output row.
+#include "gemm_kernel.h"
+#include <cstdlib>
+
+using namespace sdg;
+
+namespace {
+
+constexpr int kTT = 64;                       // token rows per workgroup tile
+constexpr int kWaves = 8;
+constexpr int kFT = 32 * kWaves;              // features per workgroup tile (the last tile of a layer may be half full: N is a multiple of 128)
+constexpr int kCK = 384, kCS = kCK / 32;      // columns / k-slabs per staged chunk
+constexpr int kRow = 144;                     // LDS row of a (token, slab): plane h 64 B | plane l 64 B | 16 B (odd multiple of the 16-byte slot: conflict-free fragment reads)
+constexpr int kSlabLds = kTT * kRow;
+constexpr int kFragSet = 4096;                // bytes of one (32-feature block, k-slab): [plane 2][k-step 2][lane 64][16 B]
+
+enum { kAPlain = 0, kALayerNorm = 1 };
+enum { kEpiBias = 0, kEpiGelu = 1, kEpiResid = 2 };
+
+struct TokArgs {
+  const float* x;        // [M][lda] rows
+  const char* wp;        // packed weight planes (sixdgs_tok_pack): [N / 32][K / 32][kFragSet]
+  const float* winv;     // [N] reciprocal row scales of the packed weights
+  const float* bias;     // [N] or null
+  const float* ln_g;     // [K] LayerNorm weight / bias (kALayerNorm)
+  const float* ln_b;
+  const float* res;      // [M][ldr] residual stream (kEpiResid)
+  const float* gamma;    // [N] LayerScale (kEpiResid; null = 1)
+  float* y;              // [M][ldy]
+  int64_t m, lda, ldy, ldr;
+  int n, k;
+  float ln_eps;
+  int ft_per_wg;         // feature tiles a workgroup walks over
+};
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): 1 - (a1 t + .. + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(1.f - p * t * e, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)); }
+
+// butterflies over the 16 lanes of a DPP row (a token row's 16 lanes): rotations by 8 and 4 within the row, then the two quad permutations -- four VALU
+// operations with a DPP operand each, no LDS traffic (the generic __shfl_xor goes through ds_bpermute_b32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float red16_sum(float v) {
+  v += dpp_f<0x128>(v);      // row_ror:8
+  v += dpp_f<0x124>(v);      // row_ror:4
+  v += dpp_f<0x4e>(v);       // quad_perm:[2,3,0,1]
+  v += dpp_f<0xb1>(v);       // quad_perm:[1,0,3,2]
+  return v;
+}
+__device__ __forceinline__ float red16_max(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x4e>(v));
+  v = fmaxf(v, dpp_f<0xb1>(v));
+  return v;
+}
+
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+#ifdef SDG_TOK_PROF      // developer build (SIXDGS_EXTRA_FLAGS=-DSDG_TOK_PROF, tools/prof_tok.py): cycle stamps of workgroup (0, 0)'s sections
+__device__ long long g_tok_prof[16];
+#define TOK_T(K) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_tok_prof[K] = wall_clock64();
+#else
+#define TOK_T(K)
+#endif
+
+// MULTI: the contraction has more than one chunk of 384 columns (FC2): every chunk is staged with its own row scales and folded into a second
+// accumulator set; single-chunk layers scale their one accumulator set in the epilogue.
+template <int AMODE, int EPI, bool MULTI, int PFW>
+__global__ void __launch_bounds__(64 * kWaves) k_tok_gemm(TokArgs A) {
+  static_assert(kCS % PFW == 0, "the ring of weight fragments in flight divides the slabs of a chunk");
+  __shared__ __attribute__((aligned(16))) char sa[kCS * kSlabLds];                    // the token tile's planes: [slab][token][kRow]
+  __shared__ __attribute__((aligned(16))) float lnp[AMODE == kALayerNorm ? 2 * kCK : 4];
+  __shared__ float inv_as[kTT];                                                        // reciprocal scale of every token row of the staged chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * kTT;
+  const int n_fb = A.n >> 5;                                                            // 32-feature blocks of the layer
+  const int n_ft = (A.n + kFT - 1) / kFT;
+  const int ft0 = (int)blockIdx.y * A.ft_per_wg;
+  const int ft1 = ft0 + A.ft_per_wg < n_ft ? ft0 + A.ft_per_wg : n_ft;
+  const int KS = A.k >> 5, KC = MULTI ? A.k / kCK : 1;
+  TOK_T(0)
+
+  // ---- weight fragments: PFW (block, slab) sets in flight; the cursor runs on over chunks and feature tiles and stops on the wave's last set -----------
+  // (a wave whose block lies beyond the layer in the last, half-full tile reads block 0 and stores nothing)
+  uint4 wf[PFW][4];
+  int pf_gs = 0, pf_ft = ft0;
+  const char* const wlane = A.wp + lane * 16;
+  auto blk_of = [&](const int ft) { const int b = ft * kWaves + wave; return b < n_fb ? b : 0; };
+  size_t pf_blk = (size_t)blk_of(ft0) * KS;
+  auto issue = [&](const int slot) {
+    const char* p = wlane + (pf_blk + pf_gs) * kFragSet;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wf[slot][q] = *reinterpret_cast<const uint4*>(p + q * 1024);
+    if (pf_gs + 1 < KS) {
+      ++pf_gs;
+    } else if (pf_ft + 1 < ft1) {
+      ++pf_ft;
+      pf_gs = 0;
+      pf_blk = (size_t)blk_of(pf_ft) * KS;
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < PFW; ++s) issue(s);
+
+  if (AMODE == kALayerNorm) {
+    for (int i = tid; i < kCK; i += 64 * kWaves) { lnp[i] = A.ln_g[i]; lnp[kCK + i] = A.ln_b[i]; }
+    __syncthreads();
+  }
+
+  // ---- staging of chunk c of the token tile: 16 lanes per row, 4 rows per wave and pass, 2 passes ---------------------------------------------------------
+  auto stage = [&](const int c) {
+    const int sub = lane & 15, tq = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < kTT / (4 * kWaves); ++p) {
+      const int t = p * 4 * kWaves + wave * 4 + tq;
+      const int64_t gr = row0 + t < A.m ? row0 + t : A.m - 1;                           // rows beyond M: a valid row is read, nothing is stored
+      const float* src = A.x + gr * A.lda + c * kCK + 4 * sub;
+      float4 v[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = *reinterpret_cast<const float4*>(src + i * 64);
+      if (AMODE == kALayerNorm) {      // torch.nn.LayerNorm: biased variance around the mean, two passes over the registers
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = red16_sum(s1) * (1.f / kCK);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+          s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = rsqrtf(red16_sum(s2) * (1.f / kCK) + A.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const float4 g = *reinterpret_cast<const float4*>(lnp + 4 * (sub + 16 * i)), b = *reinterpret_cast<const float4*>(lnp + kCK + 4 * (sub + 16 * i));
+          v[i].x = v[i].x * rstd * g.x + b.x; v[i].y = v[i].y * rstd * g.y + b.y; v[i].z = v[i].z * rstd * g.z + b.z; v[i].w = v[i].w * rstd * g.w + b.w;
+        }
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+      mx = red16_max(mx);
+      const float sc = f3_scale(mx);                                                     // row maximum to [2^13, 2^14): exact power of two
+      if (sub == 0) inv_as[t] = f3_inv_scale(mx);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float e[4] = {v[i].x * sc, v[i].y * sc, v[i].z * sc, v[i].w * sc};
+        f16x4_t h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const _Float16 hh = (_Float16)e[j];
+          h[j] = hh;
+          l[j] = (_Float16)(e[j] - (float)hh);
+        }
+        char* d = sa + ((2 * i + (sub >> 3)) * kTT + t) * kRow + (sub & 7) * 8;         // columns 4 (sub + 16 i) .. + 3: slab 2 i + (sub >> 3), position 4 (sub & 7)
+        *reinterpret_cast<f16x4_t*>(d) = h;
+        *reinterpret_cast<f16x4_t*>(d + 64) = l;
+      }
+    }
+  };
+
+  const int tokl = lane & 31, half = lane >> 5;
+  const char* fr = sa + tokl * kRow + half * 16;                                         // this lane's fragment pieces: + (slab * 64 + 32 tt) * kRow + plane * 64 + kstep * 32
+  for (int ft = ft0; ft < ft1; ++ft) {
+    const int fb = ft * kWaves + wave;
+    const bool active = fb < n_fb;                                                       // (wave-uniform)
+    const int fw = (active ? fb : 0) * 32 + 4 * half;                                    // this lane's features: fw + 8 rg + j
+    // the epilogue's per-feature constants: requested now, used behind the slab loop
+    float4 iw[4], bv[4], gv[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      iw[rg] = *reinterpret_cast<const float4*>(A.winv + fw + 8 * rg);
+      bv[rg] = A.bias ? *reinterpret_cast<const float4*>(A.bias + fw + 8 * rg) : float4{0.f, 0.f, 0.f, 0.f};
+      gv[rg] = (EPI == kEpiResid && A.gamma) ? *reinterpret_cast<const float4*>(A.gamma + fw + 8 * rg) : float4{1.f, 1.f, 1.f, 1.f};
+    }
+    f32x16 tot[2];
+    f32x16 acc[2];
+    if (MULTI) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { tot[0][i] = 0.f; tot[1][i] = 0.f; }
+    }
+#pragma unroll 1
+    for (int c = 0; c < KC; ++c) {      // chunks of the contraction: ONE copy of the staging and of the slab loop in the code
+      if (ft == ft0 || MULTI) {
+        if (c > 0 || ft > ft0) __syncthreads();                                          // every wave is done with the planes about to be overwritten
+        TOK_T(1)
+        stage(c);
+        __syncthreads();
+        TOK_T(2)
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < kCS; ++s) {
+        const int slot = s % PFW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f16x8_t b[2][2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) b[tt][pl] = *reinterpret_cast<const f16x8_t*>(fr + (s * kTT + 32 * tt) * kRow + pl * 64 + j * 32);
+          const f16x8_t wh = __builtin_bit_cast(f16x8_t, wf[slot][j]), wl = __builtin_bit_cast(f16x8_t, wf[slot][2 + j]);
+          // (weight plane, token plane): l*h, h*l, h*h -- smallest magnitude first
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b[tt][0], acc[tt], 0, 0, 0);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[tt][1], acc[tt], 0, 0, 0);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b[tt][0], acc[tt], 0, 0, 0);
+        }
+        issue(slot);
+      }
+      if (MULTI) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const float ia = inv_as[32 * tt + tokl];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tot[tt][i] += acc[tt][i] * ia;
+        }
+      }
+      TOK_T(3)
+    }
+
+    // ---- epilogue: lane = token tokl (+ 32 tt), register 4 rg + j = feature 8 rg + 4 half + j of the wave's 32 ---------------------------------------------
+    if (active) {
+      float4 r4[2][4];
+      bool live[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int64_t gr = row0 + 32 * tt + tokl;
+        live[tt] = gr < A.m;
+        if (EPI == kEpiResid) {
+          const float* rp = A.res + (live[tt] ? gr : A.m - 1) * A.ldr + fw;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) r4[tt][rg] = *reinterpret_cast<const float4*>(rp + 8 * rg);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float ia = MULTI ? 1.f : inv_as[32 * tt + tokl];
+        float* const yp = A.y + (row0 + 32 * tt + tokl) * A.ldy + fw;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x16& a = MULTI ? tot[tt] : acc[tt];
+          float4 v = {fmaf(a[4 * rg] * ia, iw[rg].x, bv[rg].x), fmaf(a[4 * rg + 1] * ia, iw[rg].y, bv[rg].y), fmaf(a[4 * rg + 2] * ia, iw[rg].z, bv[rg].z),
+                      fmaf(a[4 * rg + 3] * ia, iw[rg].w, bv[rg].w)};
+          if (EPI == kEpiGelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          if (EPI == kEpiResid) {
+            v.x = fmaf(gv[rg].x, v.x, r4[tt][rg].x); v.y = fmaf(gv[rg].y, v.y, r4[tt][rg].y); v.z = fmaf(gv[rg].z, v.z, r4[tt][rg].z); v.w = fmaf(gv[rg].w, v.w, r4[tt][rg].w);
+          }
+          if (live[tt]) *reinterpret_cast<float4*>(yp + 8 * rg) = v;
+        }
+      }
+    }
+    TOK_T(4)
+  }
+}
+
+// fp32 weights [n][ldw] -> the packed planes of k_tok_gemm + reciprocal row scales.  One workgroup per block of 32 rows.
+__global__ void __launch_bounds__(256) k_tok_pack(const float* __restrict__ w, int k, int64_t ldw, char* __restrict__ planes, float* __restrict__ winv) {
+  __shared__ float rmax[32];
+  const int tid = threadIdx.x, fb = blockIdx.x;
+  {
+    const int row = tid >> 3, part = tid & 7;
+    const float* src = w + (int64_t)(fb * 32 + row) * ldw;
+    float mx = 0.f;
+    for (int c = part; c < k; c += 8) mx = fmaxf(mx, fabsf(src[c]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    if (part == 0) { rmax[row] = mx; winv[fb * 32 + row] = f3_inv_scale(mx); }
+  }
+  __syncthreads();
+  const int KS = k >> 5;
+  for (int idx = tid; idx < KS * 128; idx += 256) {
+    const int gs = idx >> 7, j = (idx >> 6) & 1, l = idx & 63;
+    const int row = l & 31, k0 = gs * 32 + j * 16 + 8 * (l >> 5);
+    const float* src = w + (int64_t)(fb * 32 + row) * ldw + k0;
+    const float sc = f3_scale(rmax[row]);
+    f16x8_t h, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = src[e] * sc;
+      const _Float16 hh = (_Float16)x;
+      h[e] = hh;
+      lo[e] = (_Float16)(x - (float)hh);
+    }
+    char* d = planes + ((size_t)(fb * KS + gs) * 4 + j) * 1024 + l * 16;
+    *reinterpret_cast<f16x8_t*>(d) = h;
+    *reinterpret_cast<f16x8_t*>(d + 2048) = lo;
+  }
+}
+
+int tok_ft_per_wg(int64_t token_tiles, int n_ft, bool multi) {
+  if (multi) return 1;                                     // every chunk re-stages the token tile: nothing to share between feature tiles
+  static const int forced = [] { const char* e = getenv("SIXDGS_TOK_FTPW"); return e ? atoi(e) : 0; }();      // (developer hook: tools/time_vit_gemms.py)
+  if (forced > 0) return forced < n_ft ? forced : n_ft;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int64_t per = sdg_cdiv(token_tiles * n_ft, cus);    // as many workgroups as there are compute units (one resident per unit: 110 KB of LDS), no more
+  return (int)(per < 1 ? 1 : (per > n_ft ? n_ft : per));
+}
+
+template <int AMODE, bool MULTI>
+int launch_tok(TokArgs& A, int epi, hipStream_t s) {
+  const int64_t tt = sdg_cdiv(A.m, kTT);
+  const int n_ft = (A.n + kFT - 1) / kFT;
+  A.ft_per_wg = tok_ft_per_wg(tt, n_ft, MULTI);
+  if (tt > 0x7fffffffLL) return SIXDGS_E_BADARG;
+  const dim3 g((unsigned)tt, (unsigned)sdg_cdiv(n_ft, A.ft_per_wg)), b(64 * kWaves);
+  constexpr int PFW = 4;
+  switch (epi) {
+    case kEpiBias: hipLaunchKernelGGL((k_tok_gemm<AMODE, kEpiBias, MULTI, PFW>), g, b, 0, s, A); break;
+    case kEpiGelu: hipLaunchKernelGGL((k_tok_gemm<AMODE, kEpiGelu, MULTI, PFW>), g, b, 0, s, A); break;
+    case kEpiResid: hipLaunchKernelGGL((k_tok_gemm<AMODE, kEpiResid, MULTI, PFW>), g, b, 0, s, A); break;
+    default: return SIXDGS_E_BADARG;
+  }
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+}  // namespace
+
+#ifdef SDG_TOK_PROF
+extern "C" int sixdgs_debug_tok_prof(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tok_prof), sizeof(long long) * 16); }
+#endif
+
+extern "C" {
+
+size_t sixdgs_tok_pack_bytes(int n, int k) { return n > 0 && k > 0 ? (size_t)n * (size_t)k * 4 : 0; }
+
+int sixdgs_tok_pack(const float* w, int n, int k, int64_t ldw, void* planes, float* inv_scale, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(w && planes && inv_scale && n > 0 && (n % 128) == 0 && k > 0 && (k % kCK) == 0 && ldw >= k);
+  SDG_CHECK_ARG(((uintptr_t)planes % 16) == 0);
+  hipLaunchKernelGGL(k_tok_pack, dim3((unsigned)(n / 32)), dim3(256), 0, sdg_stream(stream), w, k, ldw, static_cast<char*>(planes), inv_scale);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+// y = epilogue( prologue(x) . w^T + bias ): see include/sixdgs.h
+int sixdgs_tok_linear(const float* x, int64_t m, int k, int64_t ldx, int a_mode, const float* ln_weight, const float* ln_bias, float ln_eps,
+                      const void* w_planes, const float* w_inv_scale, const float* bias, int n, int epilogue, const float* residual, int64_t ldr,
+                      const float* gamma, float* y, int64_t ldy, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(m >= 0 && n > 0 && (n % 128) == 0 && k > 0 && (k % kCK) == 0);
+  if (m == 0) return 0;
+  SDG_CHECK_ARG(x && w_planes && w_inv_scale && y && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_planes % 16) == 0 && ((uintptr_t)y % 16) == 0);
+  SDG_CHECK_ARG(((uintptr_t)w_inv_scale % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && (!gamma || ((uintptr_t)gamma % 16) == 0));
+  SDG_CHECK_ARG(a_mode == kAPlain || a_mode == kALayerNorm);
+  SDG_CHECK_ARG(epilogue >= kEpiBias && epilogue <= kEpiResid);
+  SDG_CHECK_ARG((ldx % 4) == 0 && ldx >= k);
+  SDG_CHECK_ARG(a_mode != kALayerNorm || (k == kCK && ln_weight && ln_bias));                    // the LayerNorm prologue owns whole rows of 384
+  SDG_CHECK_ARG(epilogue != kEpiResid || (residual && ldr >= n && (ldr % 4) == 0 && ((uintptr_t)residual % 16) == 0));
+  SDG_CHECK_ARG(ldy >= n && (ldy % 4) == 0);
+  TokArgs A = {x, static_cast<const char*>(w_planes), w_inv_scale, bias, ln_weight, ln_bias, residual, gamma, y, m, ldx, ldy, ldr, n, k, ln_eps, 1};
+  hipStream_t s = sdg_stream(stream);
+  if (a_mode == kALayerNorm) return launch_tok<kALayerNorm, false>(A, epilogue, s);
+  if (k == kCK) return launch_tok<kAPlain, false>(A, epilogue, s);
+  return launch_tok<kAPlain, true>(A, epilogue, s);
+}
+
+}  // extern "C"

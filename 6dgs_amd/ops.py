@@ -364,6 +364,74 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
     return y
 
 
+TOK_A_PLAIN, TOK_A_LAYERNORM = 0, 1
+TOK_EPI_BIAS, TOK_EPI_GELU, TOK_EPI_RESID = 0, 1, 2
+
+
+class TokWeights:
+    """A dense layer's weight matrix [n, k] as sixdgs_tok_linear wants it: two scaled fp16 planes in the matrix pipe's operand order + reciprocal row
+    scales (sixdgs_tok_pack; n a multiple of 128, k of 384).  Built once per weight tensor: `TokWeights.of(w)` keeps the pack on a side table keyed
+    by the tensor OBJECT (weak reference), its storage address and its version counter, so an optimiser step, load_state_dict, .to() or a new tensor
+    that happens to land on a freed tensor's address re-packs."""
+    _cache: dict = {}
+
+    def __init__(self, w: torch.Tensor):
+        w = _f32(w)
+        _need_gpu(w)
+        self.n, self.k = int(w.shape[0]), int(w.shape[1])
+        lib = _lib.load()
+        self.planes = torch.empty(lib.sixdgs_tok_pack_bytes(self.n, self.k), dtype=torch.uint8, device=w.device)
+        self.inv_scale = torch.empty(self.n, dtype=torch.float32, device=w.device)
+        check(lib.sixdgs_tok_pack(_p(w), self.n, self.k, w.stride(0), _p(self.planes), _p(self.inv_scale), _stream()), "tok_pack")
+
+    @classmethod
+    def of(cls, w: torch.Tensor) -> "TokWeights":
+        import weakref
+        key = id(w)
+        hit = cls._cache.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+            return hit[3]
+        if w.dim() != 2:
+            raise RuntimeError(f"6dgs_amd: a dense layer's weight is [n, k], got {tuple(w.shape)}")
+        with torch.cuda.device(w.device):
+            tw = cls(w)
+        if len(cls._cache) > 512:
+            for k_ in [k_ for k_, v_ in cls._cache.items() if v_[0]() is None]:
+                del cls._cache[k_]
+        cls._cache[key] = (weakref.ref(w), w._version, w.data_ptr(), tw)
+        return tw
+
+
+@_on_device
+def tok_linear(x: torch.Tensor, w, b: Optional[torch.Tensor] = None, *, ln=None, epilogue: int = TOK_EPI_BIAS, residual: Optional[torch.Tensor] = None,
+               gamma: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The backbone stage's dense product with its neighbours folded in (include/sixdgs.h: sixdgs_tok_linear).  w: the layer's weight [n, k] (packed
+    on first use, TokWeights.of) or a TokWeights.
+      x [M, K] rows (row stride free);  ln=(weight, bias, eps): LayerNorm over K = 384 in front of the product;
+      epilogue TOK_EPI_BIAS / _GELU / _RESID (residual [M, N] + gamma [N] * (. + b); out may be the residual tensor)."""
+    tw = w if isinstance(w, TokWeights) else TokWeights.of(w)
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.dim() != 2 or x.shape[1] != tw.k:
+        raise RuntimeError(f"6dgs_amd: tok_linear needs x [M, {tw.k}], got {tuple(x.shape)}")
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    _need_gpu(x, tw.planes)
+    b = _f32(b) if b is not None else None
+    n, k = tw.n, tw.k
+    a_mode, ln_w, ln_b, eps = TOK_A_PLAIN, None, None, 0.0
+    if ln is not None:
+        a_mode, ln_w, ln_b, eps = TOK_A_LAYERNORM, _f32(ln[0]), _f32(ln[1]), float(ln[2])
+    m = x.shape[0]
+    y = out if out is not None else torch.empty(m, n, device=x.device)
+    res = _f32(residual) if residual is not None else None
+    check(_lib.load().sixdgs_tok_linear(_p(x), m, k, x.stride(0), a_mode, _p(ln_w), _p(ln_b), eps, _p(tw.planes), _p(tw.inv_scale), _p(b), n, int(epilogue),
+                                        _p(res), res.stride(0) if res is not None else 0, _p(_f32(gamma)) if gamma is not None else None, _p(y), y.stride(0),
+                                        _stream()), "tok_linear")
+    return y
+
+
 @_on_device
 def split_planes_f16(x: torch.Tensor):
     """fp32 [rows,384] -> (scaled fp16 planes as uint8 [rows,1536], reciprocal power-of-two scale of every 128-row tile)."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion); the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -229,6 +229,28 @@ size_t sixdgs_linear_splitk_workspace_bytes(int64_t m, int n, int slices);
 int sixdgs_linear_splitk(const float* x, int64_t m, int k, int64_t ldx, const float* w, int64_t ldw, const float* b, int n,
                          int relu, float* y, int64_t ldy, int slices, void* ws, size_t ws_bytes, sixdgs_stream_t stream,
                          int mma_mode);
+
+/* The dense products of the backbone stage (pose_estimation/backbone.py:82-114 runs DINOv2 ViT-S/14 on every query image) with the
+ * elementwise work around them folded in: y = epilogue( prologue(x) . w^T + bias ), fp32 results (two scaled fp16 planes per operand, three cross terms,
+ * fp32 accumulation), tiles of 64 token rows x 256 features -- sized for token matrices of 257 .. 4112 rows.  The weights are constants and are split
+ * ONCE: sixdgs_tok_pack turns w [n][ldw] (n a multiple of 128, k a multiple of 384) into sixdgs_tok_pack_bytes(n, k) bytes of planes in the matrix
+ * pipe's operand order + n reciprocal row scales; sixdgs_tok_linear takes those.
+ *   a_mode   SIXDGS_TOK_A_PLAIN  x [m][ldx];
+ *            SIXDGS_TOK_A_LAYERNORM  LayerNorm(x; ln_weight, ln_bias, ln_eps) over the k = 384 columns in front of the product (torch.nn.LayerNorm,
+ *                                dinov2 block.norm1 / norm2);
+ *   epilogue SIXDGS_TOK_EPI_BIAS  y [m][ldy] = acc + bias;   SIXDGS_TOK_EPI_GELU  gelu(acc + bias), erf form (mlp.fc1 + act; erf to 1.5e-7);
+ *            SIXDGS_TOK_EPI_RESID  residual [m][ldr] + gamma[n] * (acc + bias) (x + ls(branch(x)): attn.proj / mlp.fc2, LayerScale gamma or NULL = 1;
+ *                                y may be the residual buffer itself). */
+#define SIXDGS_TOK_A_PLAIN 0
+#define SIXDGS_TOK_A_LAYERNORM 1
+#define SIXDGS_TOK_EPI_BIAS 0
+#define SIXDGS_TOK_EPI_GELU 1
+#define SIXDGS_TOK_EPI_RESID 2
+size_t sixdgs_tok_pack_bytes(int n, int k);
+int sixdgs_tok_pack(const float* w /*[n][ldw]*/, int n, int k, int64_t ldw, void* planes, float* inv_scale /*[n]*/, sixdgs_stream_t stream);
+int sixdgs_tok_linear(const float* x, int64_t m, int k, int64_t ldx, int a_mode, const float* ln_weight, const float* ln_bias, float ln_eps,
+                      const void* w_planes, const float* w_inv_scale, const float* bias /*[n] or NULL*/, int n, int epilogue, const float* residual,
+                      int64_t ldr, const float* gamma, float* y, int64_t ldy, sixdgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scorer, image side (per batch of query images)

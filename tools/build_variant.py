@@ -9,7 +9,7 @@ out = os.path.join(ROOT, "build", "variants", f"lib_{name}.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-function", *flags]
 objs, procs = [], []
-for f in ("geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip"):
+for f in ("geometry.hip", "gemm.hip", "dense.hip", "score.hip", "pose.hip", "vit.hip"):
     o = os.path.join(ROOT, "build", "variants", f"{name}_{f[:-4]}.o")
     objs.append(o)
     procs.append(subprocess.Popen(base + ["-c", os.path.join(csrc, f), "-o", o]))
