@@ -42,9 +42,10 @@ class CameraDirectionPredictor(torch.nn.Module):
         return y[0] if single else y
 
     def _forward_gemm(self, x):
-        """Inference on the GPU: each valid convolution of the 16x16 map is im2col (F.unfold, same (c, kh, kw) order as
-        conv.weight.view(out, -1)) + the library's MFMA `linear` with the bias/ReLU epilogue.  MIOpen has no tuned fp32
-        solver for 384-channel 5x5 on 16x16 and falls back to naive_conv (2.7 ms per image in the round-1 trace)."""
+        """Inference on the GPU: each valid convolution of the 16x16 map is im2col (ops.im2col: the whole batch in one launch, columns in the (c, kh, kw)
+        order of conv.weight.view(out, -1), the previous layer's GEMM output read in place through a permuted view) + the library's MFMA `linear` with
+        the bias/ReLU epilogue.  MIOpen has no tuned fp32 solver for 384-channel 5x5 on 16x16 and falls back to naive_conv (2.7 ms per image in the
+        round-1 trace); F.unfold launches one im2col kernel per image and needed a transposing copy (rounds 2-5: 1.1 ms of a 16-image step)."""
         from . import ops
 
         b = x.shape[0]
@@ -54,9 +55,7 @@ class CameraDirectionPredictor(torch.nn.Module):
                     continue
                 k = layer.kernel_size[0]
                 ho, wo = x.shape[2] - k + 1, x.shape[3] - k + 1
-                cols = torch.nn.functional.unfold(x, k)                       # [B, C*k*k, ho*wo]
-                a = cols.transpose(1, 2).reshape(b * ho * wo, -1).contiguous()
-                y = ops.linear(a, layer.weight.reshape(layer.weight.shape[0], -1), layer.bias, relu=True)
-                x = y.reshape(b, ho, wo, -1).permute(0, 3, 1, 2).contiguous()
+                y = ops.linear(ops.im2col(x, k), layer.weight.reshape(layer.weight.shape[0], -1), layer.bias, relu=True)      # [b * ho * wo, out]
+                x = y.view(b, ho, wo, -1).permute(0, 3, 1, 2)                                                                 # [b, out, ho, wo], no copy
         h = ops.linear(x.reshape(b, -1).contiguous(), self.mlp[0].weight, self.mlp[0].bias, relu=True)
         return ops.linear(h, self.mlp[2].weight, self.mlp[2].bias, relu=False)

@@ -327,6 +327,48 @@ __global__ void __launch_bounds__(256) k_tok_pack(const float* __restrict__ w, i
   }
 }
 
+// a22's convolutions as GEMMs (camera_direction_network.py:29-36: valid k x k convolutions of the 16 x 16 feature map): the A matrix of a whole batch in
+// ONE launch -- row (b, oy, ox), column (c, ky, kx) = x[b][c][oy + ky][ox + kx], the order of conv.weight.view(out, -1) -- from a feature map with FREE
+// strides, so the previous layer's GEMM output [B * ho * wo][C] is read where it lies (no permute copy).  PyTorch's unfold launches one im2col kernel
+// per IMAGE (64 launches of ~8 us for 16 images and four layers) and needed a transposing copy behind it.  One thread = one (row, channel): k * k
+// consecutive outputs.
+__global__ void __launch_bounds__(256) k_im2col(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int C, int k, int ho, int wo,
+                                                int64_t total, float* __restrict__ a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (row, channel), channel fastest
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t row = i / C;
+  const int ox = (int)(row % wo);
+  const int64_t t = row / wo;
+  const int oy = (int)(t % ho);
+  const int64_t b = t / ho;
+  const float* src = x + b * sb + c * sc + oy * sy + ox * sx;
+  float* dst = a + (row * C + c) * (int64_t)(k * k);
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) dst[ky * k + kx] = src[ky * sy + kx * sx];
+}
+
+// a16's first step for a batch (pose_estimation/test.py:69-73: uint8 image / 255.0): [B][H][W][3] uint8 -> [B][3][H][W] fp32 through the caller's
+// 256-entry table (built on the CPU with the reference's true division), planar so that the resize that follows reads contiguous rows.  Replaces
+// stack + .long() + table lookup + stack + channels-last copy (five PyTorch kernels, 0.32 ms for 16 images of 800 x 800) with one pass.
+__global__ void __launch_bounds__(256) k_u8_to_planar(const uint8_t* __restrict__ in, const float* __restrict__ lut, int64_t hw, int64_t total4, float* __restrict__ out) {
+  __shared__ float tab[256];
+  tab[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  // one thread = 4 consecutive pixels of one image: 12 bytes in, 3 x 16 bytes out
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t per = hw >> 2;
+    const int64_t b = i / per, p4 = i - b * per;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (b * hw + 4 * p4) * 3);
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+    const uint8_t px[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24), (uint8_t)w1, (uint8_t)(w1 >> 8), (uint8_t)(w1 >> 16),
+                            (uint8_t)(w1 >> 24), (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
+    float* dst = out + b * 3 * hw + 4 * p4;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(dst + c * hw) = float4{tab[px[c]], tab[px[3 + c]], tab[px[6 + c]], tab[px[9 + c]]};
+  }
+}
+
 int tok_ft_per_wg(int64_t token_tiles, int n_ft, bool multi) {
   if (multi) return 1;                                     // every chunk re-stages the token tile: nothing to share between feature tiles
   static const int forced = [] { const char* e = getenv("SIXDGS_TOK_FTPW"); return e ? atoi(e) : 0; }();      // (developer hook: tools/time_vit_gemms.py)
@@ -373,6 +415,31 @@ int sixdgs_tok_pack(const float* w, int n, int k, int64_t ldw, void* planes, flo
   SDG_CHECK_ARG(w && planes && inv_scale && n > 0 && (n % 128) == 0 && k > 0 && (k % kCK) == 0 && ldw >= k);
   SDG_CHECK_ARG(((uintptr_t)planes % 16) == 0);
   hipLaunchKernelGGL(k_tok_pack, dim3((unsigned)(n / 32)), dim3(256), 0, sdg_stream(stream), w, k, ldw, static_cast<char*>(planes), inv_scale);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_im2col(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int batch, int channels, int height, int width, int k,
+                  float* a, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && channels > 0 && k > 0 && height >= k && width >= k);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(x && a);
+  const int ho = height - k + 1, wo = width - k + 1;
+  const int64_t total = (int64_t)batch * ho * wo * channels;
+  SDG_CHECK_ARG(sdg_cdiv(total, 256) <= 0x7fffffffLL);
+  hipLaunchKernelGGL(k_im2col, dim3((unsigned)sdg_cdiv(total, 256)), dim3(256), 0, sdg_stream(stream), x, stride_b, stride_c, stride_y, stride_x, channels, k, ho, wo,
+                     total, a);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_u8_to_planar(const uint8_t* images, int batch, int64_t pixels, const float* table256, float* out, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && pixels > 0 && (pixels % 4) == 0);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(images && table256 && out && ((uintptr_t)images % 4) == 0 && ((uintptr_t)out % 16) == 0);
+  const int64_t total4 = (int64_t)batch * (pixels / 4);
+  const int64_t grid = sdg_cdiv(total4, 256);
+  hipLaunchKernelGGL(k_u8_to_planar, dim3((unsigned)(grid < 8192 ? grid : 8192)), dim3(256), 0, sdg_stream(stream), images, table256, pixels, total4, out);
   SDG_LAUNCH_OK();
   return 0;
 }

@@ -219,7 +219,8 @@ class IdentificationModule(torch.nn.Module):
         (the common case: one launch sequence for the whole batch instead of one per image)."""
         bw = self.backbone_wrapper
         if all(m is None for m in masks) and all(i.shape == imgs[0].shape for i in imgs):
-            feats = bw.features_from_norm(bw.preprocess_batch(torch.stack(list(imgs))))
+            stacked = imgs if isinstance(imgs, torch.Tensor) and imgs.dim() == 4 else torch.stack(list(imgs))      # (prepare_images_device hands over one tensor)
+            feats = bw.features_from_norm(bw.preprocess_batch(stacked))
             return bw.assemble_batch(feats)
         pre = [bw.preprocess(i, m) for i, m in zip(imgs, masks)]
         feats = bw.features_from_norm(torch.cat([p[0] for p in pre], dim=0))

@@ -364,6 +364,38 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
     return y
 
 
+@_on_device
+def im2col(x: torch.Tensor, k: int) -> torch.Tensor:
+    """[B, C, H, W] fp32 (ANY strides: a permuted view of a [B*H*W, C] GEMM output is read in place) -> the A matrix [B*ho*wo, C*k*k] of the valid
+    k x k convolution, columns in conv.weight.view(out, -1) order (sixdgs_im2col): torch.nn.functional.unfold + transpose + contiguous in one launch."""
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise RuntimeError(f"6dgs_amd: im2col needs a float32 [B, C, H, W] tensor, got {x.dtype} {tuple(x.shape)}")
+    x = x.detach()
+    _need_gpu(x)
+    b, c, h, w = x.shape
+    if h < k or w < k:
+        raise RuntimeError(f"6dgs_amd: im2col: a {k} x {k} window does not fit a {h} x {w} map")
+    a = torch.empty(b * (h - k + 1) * (w - k + 1), c * k * k, device=x.device)
+    check(_lib.load().sixdgs_im2col(_p(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), b, c, h, w, int(k), _p(a), _stream()), "im2col")
+    return a
+
+
+@_on_device
+def u8_to_planar(images_u8: torch.Tensor, table256: torch.Tensor) -> torch.Tensor:
+    """[B, H, W, 3] uint8 -> [B, 3, H, W] fp32 = table256[value] (sixdgs_u8_to_planar; H*W a multiple of 4)."""
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[-1] != 3 or (images_u8.shape[1] * images_u8.shape[2]) % 4:
+        raise RuntimeError(f"6dgs_amd: u8_to_planar needs uint8 [B, H, W, 3] with H*W a multiple of 4, got {images_u8.dtype} {tuple(images_u8.shape)}")
+    x = images_u8.contiguous()
+    t = _f32(table256)
+    _need_gpu(x, t)
+    if t.numel() != 256:
+        raise RuntimeError("6dgs_amd: u8_to_planar needs a 256-entry table")
+    b, h, w, _ = x.shape
+    out = torch.empty(b, 3, h, w, device=x.device)
+    check(_lib.load().sixdgs_u8_to_planar(_p(x), b, h * w, _p(t), _p(out), _stream()), "u8_to_planar")
+    return out
+
+
 TOK_A_PLAIN, TOK_A_LAYERNORM = 0, 1
 TOK_EPI_BIAS, TOK_EPI_GELU, TOK_EPI_RESID = 0, 1, 2
 

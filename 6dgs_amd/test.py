@@ -63,11 +63,16 @@ def prepare_image_device(img_u8: torch.Tensor):
 
 
 def prepare_images_device(images):
-    """List of uint8 device images -> (fp32 images, masks) with mask None for RGB (all-ones mask, test.py:80-83) and the
-    whole batch converted in one go when the images share a shape."""
-    if len(images) > 1 and all(im.shape == images[0].shape and im.shape[-1] == 3 for im in images):
-        obs = _u8_lut(images[0].device)[torch.stack(list(images)).long()]
-        return list(obs), [None] * len(images)
+    """uint8 device images (a list, or one stacked [B,H,W,C] tensor) -> (fp32 images, masks) with mask None for RGB (all-ones mask, test.py:80-83).
+    RGB images of one shape are converted in ONE launch (ops.u8_to_planar: the 256-entry table of _u8_lut, written planar) and come back as one
+    [B,H,W,3] tensor -- a channels-last VIEW of the planar buffer, which BackboneWrapper.preprocess_batch permutes straight back (no copy on the way
+    to the resize); it indexes / iterates like the list of images it replaces."""
+    n = len(images)
+    if n >= 1 and all(im.shape == images[0].shape and im.shape[-1] == 3 and im.dtype == torch.uint8 and im.is_cuda for im in images) \
+            and (images[0].shape[0] * images[0].shape[1]) % 4 == 0:
+        stacked = images if isinstance(images, torch.Tensor) else (images[0][None] if n == 1 else torch.stack(list(images)))
+        planar = ops.u8_to_planar(stacked, _u8_lut(stacked.device))
+        return planar.permute(0, 2, 3, 1), [None] * n
     out_i, out_m = [], []
     for im in images:
         o, m = prepare_image_device(im)
@@ -142,7 +147,7 @@ class _ImageSideGraph:
         return self.up
 
     def _vit(self, id_module):
-        imgs_f, masks = prepare_images_device(list(self.inp))
+        imgs_f, masks = prepare_images_device(self.inp)
         return id_module.image_tokens(imgs_f, masks)
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion); the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion), sixdgs_im2col, sixdgs_u8_to_planar; the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -251,6 +251,17 @@ int sixdgs_tok_pack(const float* w /*[n][ldw]*/, int n, int k, int64_t ldw, void
 int sixdgs_tok_linear(const float* x, int64_t m, int k, int64_t ldx, int a_mode, const float* ln_weight, const float* ln_bias, float ln_eps,
                       const void* w_planes, const float* w_inv_scale, const float* bias /*[n] or NULL*/, int n, int epilogue, const float* residual,
                       int64_t ldr, const float* gamma, float* y, int64_t ldy, sixdgs_stream_t stream);
+
+/* a22 (camera_direction_network.py:29-36, the valid k x k convolutions of the camera-up CNN) as GEMMs: the im2col matrix of a whole batch in one
+ * launch.  a [batch * ho * wo][channels * k * k] (ho = height - k + 1, wo = width - k + 1): row (b, oy, ox), column (c, ky, kx) =
+ * x[b * stride_b + c * stride_c + (oy + ky) * stride_y + (ox + kx) * stride_x] -- the column order of conv.weight.view(out, -1); strides in elements,
+ * free (NCHW, or the [B * ho * wo][C] output of the previous layer's GEMM read in place). */
+int sixdgs_im2col(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int batch, int channels, int height, int width, int k,
+                  float* a, sixdgs_stream_t stream);
+
+/* a16, first step, for a batch (pose_estimation/test.py:69-73: uint8 image / 255.0): images [batch][pixels][3] uint8 -> out [batch][3][pixels] fp32,
+ * out = table256[value] (the caller's table carries the reference's true division); pixels a multiple of 4. */
+int sixdgs_u8_to_planar(const uint8_t* images, int batch, int64_t pixels, const float* table256, float* out, sixdgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scorer, image side (per batch of query images)

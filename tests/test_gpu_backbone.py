@@ -221,6 +221,33 @@ def test_tok_linear_prologues_and_epilogues(ops):
         ops.tok_linear(R(10, 384), R(64, 384))           # N not a multiple of 128
 
 
+def test_im2col_and_u8_to_planar_are_exact(ops):
+    """sixdgs_im2col against torch.nn.functional.unfold (the A matrix of the camera-up CNN's valid convolutions: same values, same column order) on
+    a contiguous map and on a permuted view of a [B*H*W, C] matrix (how the previous layer's GEMM output is read in place); sixdgs_u8_to_planar
+    against the table lookup it replaces (prepare_image: uint8 / 255.0 through the CPU-built table), and prepare_images_device's one-tensor form."""
+    import torch.nn.functional as F
+    tp = importlib.import_module("6dgs_amd.test")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for b, c, h, w, k in ((3, 7, 16, 16, 5), (2, 384, 12, 12, 5), (16, 5, 4, 4, 4), (1, 3, 6, 9, 3)):
+        x = torch.randn(b, c, h, w, generator=g).cuda()
+        ref = F.unfold(x, k).transpose(1, 2).reshape(b * (h - k + 1) * (w - k + 1), c * k * k)
+        assert torch.equal(ops.im2col(x, k), ref)
+        nhwc = x.permute(0, 2, 3, 1).contiguous()                         # the same map stored [B, H, W, C]
+        assert torch.equal(ops.im2col(nhwc.view(b, h, w, c).permute(0, 3, 1, 2), k), ref)
+    with pytest.raises(RuntimeError):
+        ops.im2col(torch.zeros(1, 2, 3, 3, device="cuda"), 4)
+    imgs = [torch.randint(0, 256, (20, 14, 3), generator=g, dtype=torch.uint8).cuda() for _ in range(5)]
+    lut = tp._u8_lut(imgs[0].device)
+    planar = ops.u8_to_planar(torch.stack(imgs), lut)
+    assert planar.shape == (5, 3, 20, 14) and torch.equal(planar.permute(0, 2, 3, 1), lut[torch.stack(imgs).long()])
+    batch, masks = tp.prepare_images_device(imgs)
+    assert masks == [None] * 5 and len(batch) == 5
+    for i, im in enumerate(imgs):
+        one, m1 = tp.prepare_image_device(im)
+        assert torch.equal(batch[i], one) and bool(m1.all())
+    assert batch.permute(0, 3, 1, 2).is_contiguous()                      # what preprocess_batch hands to the resize: planar, no copy
+
+
 @pytest.mark.parametrize("images", [1, 3])
 def test_fused_vit_blocks_equal_the_unfused_module(images, monkeypatch):
     """ViTS14.forward_features with the five-launch blocks (backbone.fused_blocks; every stage forced, and the default choice by row count) against the
