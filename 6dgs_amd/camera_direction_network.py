@@ -41,11 +41,24 @@ class CameraDirectionPredictor(torch.nn.Module):
             y = self.mlp(x.reshape(x.shape[0], -1))
         return y[0] if single else y
 
+    def _taps_major_weight(self, conv):
+        """conv.weight [out, c, kh, kw] with its columns in (kh, kw, c) order, as ops.im2col(taps_major=True) lays the patches out: built once per
+        parameter version (a side table, so the module's state_dict keeps the reference's keys)."""
+        w = conv.weight
+        cache = self.__dict__.setdefault("_tm_cache", {})
+        hit = cache.get(id(conv))
+        if hit is not None and hit[0] == (w._version, w.data_ptr(), str(w.device)):
+            return hit[1]
+        wt = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+        cache[id(conv)] = ((w._version, w.data_ptr(), str(w.device)), wt)
+        return wt
+
     def _forward_gemm(self, x):
-        """Inference on the GPU: each valid convolution of the 16x16 map is im2col (ops.im2col: the whole batch in one launch, columns in the (c, kh, kw)
-        order of conv.weight.view(out, -1), the previous layer's GEMM output read in place through a permuted view) + the library's MFMA `linear` with
-        the bias/ReLU epilogue.  MIOpen has no tuned fp32 solver for 384-channel 5x5 on 16x16 and falls back to naive_conv (2.7 ms per image in the
-        round-1 trace); F.unfold launches one im2col kernel per image and needed a transposing copy (rounds 2-5: 1.1 ms of a 16-image step)."""
+        """Inference on the GPU: each valid convolution of the 16x16 map is im2col (ops.im2col: the whole batch in one launch, the previous layer's
+        GEMM output read in place through a permuted view; patches laid out taps-major, so that with the channel-contiguous maps of this path every
+        patch row is a run of plain copies, against a weight whose columns are permuted to match) + the library's MFMA `linear` with the bias/ReLU
+        epilogue.  MIOpen has no tuned fp32 solver for 384-channel 5x5 on 16x16 and falls back to naive_conv (2.7 ms per image in the round-1 trace);
+        F.unfold launches one im2col kernel per image and needed a transposing copy (rounds 2-5: 1.1 ms of a 16-image step)."""
         from . import ops
 
         b = x.shape[0]
@@ -55,7 +68,7 @@ class CameraDirectionPredictor(torch.nn.Module):
                     continue
                 k = layer.kernel_size[0]
                 ho, wo = x.shape[2] - k + 1, x.shape[3] - k + 1
-                y = ops.linear(ops.im2col(x, k), layer.weight.reshape(layer.weight.shape[0], -1), layer.bias, relu=True)      # [b * ho * wo, out]
-                x = y.view(b, ho, wo, -1).permute(0, 3, 1, 2)                                                                 # [b, out, ho, wo], no copy
+                y = ops.linear(ops.im2col(x, k, taps_major=True), self._taps_major_weight(layer), layer.bias, relu=True)      # [b * ho * wo, out]
+                x = y.view(b, ho, wo, -1).permute(0, 3, 1, 2)                                                                # [b, out, ho, wo], no copy
         h = ops.linear(x.reshape(b, -1).contiguous(), self.mlp[0].weight, self.mlp[0].bias, relu=True)
         return ops.linear(h, self.mlp[2].weight, self.mlp[2].bias, relu=False)

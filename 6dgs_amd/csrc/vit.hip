@@ -328,24 +328,32 @@ __global__ void __launch_bounds__(256) k_tok_pack(const float* __restrict__ w, i
 }
 
 // a22's convolutions as GEMMs (camera_direction_network.py:29-36: valid k x k convolutions of the 16 x 16 feature map): the A matrix of a whole batch in
-// ONE launch -- row (b, oy, ox), column (c, ky, kx) = x[b][c][oy + ky][ox + kx], the order of conv.weight.view(out, -1) -- from a feature map with FREE
-// strides, so the previous layer's GEMM output [B * ho * wo][C] is read where it lies (no permute copy).  PyTorch's unfold launches one im2col kernel
-// per IMAGE (64 launches of ~8 us for 16 images and four layers) and needed a transposing copy behind it.  One thread = one (row, channel): k * k
-// consecutive outputs.
+// ONE launch from a feature map with FREE strides, so the previous layer's GEMM output [B * ho * wo][C] is read where it lies (no permute copy).
+// PyTorch's unfold launches one im2col kernel per IMAGE (64 launches of ~8 us for 16 images and four layers) and needed a transposing copy behind it.
+// Row (b, oy, ox); column order 0: (c, ky, kx) -- conv.weight.view(out, -1) -- or 1: (ky, kx, c), which with channel-contiguous input makes every
+// (row, tap) a plain copy of C consecutive floats (the caller permutes the weight's columns once).  Consecutive threads write consecutive outputs.
+template <int ORDER, int VEC>
 __global__ void __launch_bounds__(256) k_im2col(const float* __restrict__ x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int C, int k, int ho, int wo,
                                                 int64_t total, float* __restrict__ a) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (row, channel), channel fastest
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;      // first output element of this thread
   if (i >= total) return;
-  const int c = (int)(i % C);
-  const int64_t row = i / C;
+  const int kk = k * k, cols = C * kk;
+  const int64_t row = i / cols;
+  const int j = (int)(i - row * cols);
   const int ox = (int)(row % wo);
   const int64_t t = row / wo;
   const int oy = (int)(t % ho);
   const int64_t b = t / ho;
-  const float* src = x + b * sb + c * sc + oy * sy + ox * sx;
-  float* dst = a + (row * C + c) * (int64_t)(k * k);
-  for (int ky = 0; ky < k; ++ky)
-    for (int kx = 0; kx < k; ++kx) dst[ky * k + kx] = src[ky * sy + kx * sx];
+  const float* src = x + b * sb + oy * sy + ox * sx;
+  if (ORDER == 1) {
+    const int tap = j / C, c = j - tap * C, ky = tap / k, kx = tap - ky * k;
+    const float* p = src + ky * sy + kx * sx + c * sc;
+    if (VEC == 4) *reinterpret_cast<float4*>(a + i) = *reinterpret_cast<const float4*>(p);      // (sc == 1, C % 4 == 0: checked by the launcher)
+    else a[i] = *p;
+  } else {
+    const int c = j / kk, r = j - c * kk, ky = r / k, kx = r - ky * k;
+    a[i] = src[c * sc + ky * sy + kx * sx];
+  }
 }
 
 // a16's first step for a batch (pose_estimation/test.py:69-73: uint8 image / 255.0): [B][H][W][3] uint8 -> [B][3][H][W] fp32 through the caller's
@@ -420,15 +428,22 @@ int sixdgs_tok_pack(const float* w, int n, int k, int64_t ldw, void* planes, flo
 }
 
 int sixdgs_im2col(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int batch, int channels, int height, int width, int k,
-                  float* a, sixdgs_stream_t stream) {
+                  int taps_major, float* a, sixdgs_stream_t stream) {
   SDG_CHECK_ARG(batch >= 0 && channels > 0 && k > 0 && height >= k && width >= k);
   if (batch == 0) return 0;
   SDG_CHECK_ARG(x && a);
   const int ho = height - k + 1, wo = width - k + 1;
-  const int64_t total = (int64_t)batch * ho * wo * channels;
-  SDG_CHECK_ARG(sdg_cdiv(total, 256) <= 0x7fffffffLL);
-  hipLaunchKernelGGL(k_im2col, dim3((unsigned)sdg_cdiv(total, 256)), dim3(256), 0, sdg_stream(stream), x, stride_b, stride_c, stride_y, stride_x, channels, k, ho, wo,
-                     total, a);
+  const int64_t total = (int64_t)batch * ho * wo * channels * k * k;
+  SDG_CHECK_ARG((int64_t)channels * k * k <= 0x7fffffffLL && sdg_cdiv(total, 256) <= 0x7fffffffLL);
+  hipStream_t s = sdg_stream(stream);
+  const bool vec = taps_major && stride_c == 1 && (channels % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)a % 16) == 0 && (stride_b % 4) == 0 &&
+                   (stride_y % 4) == 0 && (stride_x % 4) == 0;
+  if (vec)
+    hipLaunchKernelGGL((k_im2col<1, 4>), dim3((unsigned)sdg_cdiv(total / 4, 256)), dim3(256), 0, s, x, stride_b, stride_c, stride_y, stride_x, channels, k, ho, wo, total, a);
+  else if (taps_major)
+    hipLaunchKernelGGL((k_im2col<1, 1>), dim3((unsigned)sdg_cdiv(total, 256)), dim3(256), 0, s, x, stride_b, stride_c, stride_y, stride_x, channels, k, ho, wo, total, a);
+  else
+    hipLaunchKernelGGL((k_im2col<0, 1>), dim3((unsigned)sdg_cdiv(total, 256)), dim3(256), 0, s, x, stride_b, stride_c, stride_y, stride_x, channels, k, ho, wo, total, a);
   SDG_LAUNCH_OK();
   return 0;
 }

@@ -365,9 +365,11 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
 
 
 @_on_device
-def im2col(x: torch.Tensor, k: int) -> torch.Tensor:
+def im2col(x: torch.Tensor, k: int, taps_major: bool = False) -> torch.Tensor:
     """[B, C, H, W] fp32 (ANY strides: a permuted view of a [B*H*W, C] GEMM output is read in place) -> the A matrix [B*ho*wo, C*k*k] of the valid
-    k x k convolution, columns in conv.weight.view(out, -1) order (sixdgs_im2col): torch.nn.functional.unfold + transpose + contiguous in one launch."""
+    k x k convolution (sixdgs_im2col): columns in conv.weight.view(out, -1) order -- torch.nn.functional.unfold + transpose + contiguous in one launch --
+    or, taps_major, in (ky, kx, c) order for a weight permuted as weight.permute(0, 2, 3, 1).reshape(out, -1) (plain 16-byte copies when the input's
+    channel stride is 1)."""
     if x.dim() != 4 or x.dtype != torch.float32:
         raise RuntimeError(f"6dgs_amd: im2col needs a float32 [B, C, H, W] tensor, got {x.dtype} {tuple(x.shape)}")
     x = x.detach()
@@ -376,7 +378,8 @@ def im2col(x: torch.Tensor, k: int) -> torch.Tensor:
     if h < k or w < k:
         raise RuntimeError(f"6dgs_amd: im2col: a {k} x {k} window does not fit a {h} x {w} map")
     a = torch.empty(b * (h - k + 1) * (w - k + 1), c * k * k, device=x.device)
-    check(_lib.load().sixdgs_im2col(_p(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), b, c, h, w, int(k), _p(a), _stream()), "im2col")
+    check(_lib.load().sixdgs_im2col(_p(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), b, c, h, w, int(k), 1 if taps_major else 0, _p(a), _stream()),
+          "im2col")
     return a
 
 

@@ -253,11 +253,12 @@ int sixdgs_tok_linear(const float* x, int64_t m, int k, int64_t ldx, int a_mode,
                       int64_t ldr, const float* gamma, float* y, int64_t ldy, sixdgs_stream_t stream);
 
 /* a22 (camera_direction_network.py:29-36, the valid k x k convolutions of the camera-up CNN) as GEMMs: the im2col matrix of a whole batch in one
- * launch.  a [batch * ho * wo][channels * k * k] (ho = height - k + 1, wo = width - k + 1): row (b, oy, ox), column (c, ky, kx) =
- * x[b * stride_b + c * stride_c + (oy + ky) * stride_y + (ox + kx) * stride_x] -- the column order of conv.weight.view(out, -1); strides in elements,
- * free (NCHW, or the [B * ho * wo][C] output of the previous layer's GEMM read in place). */
+ * launch.  a [batch * ho * wo][channels * k * k] (ho = height - k + 1, wo = width - k + 1): row (b, oy, ox); column (c, ky, kx) -- the order of
+ * conv.weight.view(out, -1) -- or, taps_major != 0, (ky, kx, c) (for weights whose columns the caller permuted the same way: with channel-contiguous
+ * input every (row, tap) is then a copy of `channels` consecutive floats); value x[b * stride_b + c * stride_c + (oy + ky) * stride_y + (ox + kx) * stride_x],
+ * strides in elements, free (NCHW, or the [B * ho * wo][C] output of the previous layer's GEMM read in place). */
 int sixdgs_im2col(const float* x, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int batch, int channels, int height, int width, int k,
-                  float* a, sixdgs_stream_t stream);
+                  int taps_major, float* a, sixdgs_stream_t stream);
 
 /* a16, first step, for a batch (pose_estimation/test.py:69-73: uint8 image / 255.0): images [batch][pixels][3] uint8 -> out [batch][3][pixels] fp32,
  * out = table256[value] (the caller's table carries the reference's true division); pixels a multiple of 4. */

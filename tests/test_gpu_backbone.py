@@ -233,7 +233,10 @@ def test_im2col_and_u8_to_planar_are_exact(ops):
         ref = F.unfold(x, k).transpose(1, 2).reshape(b * (h - k + 1) * (w - k + 1), c * k * k)
         assert torch.equal(ops.im2col(x, k), ref)
         nhwc = x.permute(0, 2, 3, 1).contiguous()                         # the same map stored [B, H, W, C]
-        assert torch.equal(ops.im2col(nhwc.view(b, h, w, c).permute(0, 3, 1, 2), k), ref)
+        view = nhwc.view(b, h, w, c).permute(0, 3, 1, 2)
+        assert torch.equal(ops.im2col(view, k), ref)
+        tm = ref.view(-1, c, k * k).transpose(1, 2).reshape(ref.shape[0], -1)        # columns (ky, kx, c) instead of (c, ky, kx)
+        assert torch.equal(ops.im2col(view, k, taps_major=True), tm) and torch.equal(ops.im2col(x, k, taps_major=True), tm)
     with pytest.raises(RuntimeError):
         ops.im2col(torch.zeros(1, 2, 3, 3, device="cuda"), 4)
     imgs = [torch.randint(0, 256, (20, 14, 3), generator=g, dtype=torch.uint8).cuda() for _ in range(5)]
