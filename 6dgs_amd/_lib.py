@@ -64,6 +64,7 @@ SIGNATURES = {
     "sixdgs_score_topk_ex": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, sz, vp, C.POINTER(Profile), i32]),
     "sixdgs_score_select_workspace_bytes": (sz, [i64, i32, i32, i32]),
     "sixdgs_score_select": (i32, [vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp, C.POINTER(Profile)]),
+    "sixdgs_tok_attention": (i32, [vp, i64, i32, i32, i32, vp, i64, vp]),
     "sixdgs_im2col": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sixdgs_u8_to_planar": (i32, [vp, i32, i64, vp, vp, vp]),
     "sixdgs_tok_pack_bytes": (sz, [i32, i32]),

@@ -160,7 +160,7 @@ class ViTS14(torch.nn.Module):
 # From how many token rows (257 x images) each dense stage of a block runs through sixdgs_tok_linear instead of PyTorch's kernels: GPU time per stage
 # inside a hipGraph on MI355X, profiles/r06_vit_stages.md.  Below ~8 images the library's launch-bound 8 us GEMMs win on the two N = 384 products
 # (proj, FC2: a 64-token tile gives them 10 .. 30 workgroups), while the two LayerNorm-fused ones win from 2 images (LN + FC1 + GELU always).
-FUSED_MIN_ROWS = {"qkv": 2 * 257, "proj": 8 * 257, "fc1": 0, "fc2": 16 * 257}
+FUSED_MIN_ROWS = {"qkv": 2 * 257, "attn": 0, "proj": 8 * 257, "fc1": 0, "fc2": 16 * 257}
 
 
 def fused_blocks_usable(vit, t) -> bool:
@@ -179,7 +179,7 @@ def fused_blocks_usable(vit, t) -> bool:
 def fused_blocks(blocks, t: torch.Tensor) -> torch.Tensor:
     """x + ls1(attn(norm1(x))), then x + ls2(mlp(norm2(x))) for every block (_Block.forward; dinov2's NestedTensorBlock at inference) as FIVE launches:
          LayerNorm + QKV product + bias                              (sixdgs_tok_linear: A_LAYERNORM, EPI_BIAS)
-         attention on strided views of that [M, 1152] matrix         (F.scaled_dot_product_attention; its output is token-major: no copies either side)
+         attention on that [M, 1152] matrix as it lies, token-major out  (sixdgs_tok_attention; F.scaled_dot_product_attention on strided views otherwise)
          proj + bias, LayerScale, residual                           (A_PLAIN, EPI_RESID, in place on the residual stream)
          LayerNorm + FC1 + bias + GELU                               (A_LAYERNORM, EPI_GELU)
          FC2 + bias, LayerScale, residual                            (A_PLAIN, EPI_RESID, in place)
@@ -205,8 +205,11 @@ def fused_blocks(blocks, t: torch.Tensor) -> torch.Tensor:
             qkv = ops.tok_linear(x, blk.attn.qkv.weight, blk.attn.qkv.bias, ln=(blk.norm1.weight, blk.norm1.bias, blk.norm1.eps))
         else:
             qkv = blk.attn.qkv(blk.norm1(x))
-        q, k, v = qkv.view(b, n, 3, h, c // h).permute(2, 0, 3, 1, 4).unbind(0)
-        y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(m, c)
+        if own["attn"] and n <= ops.TOK_ATTENTION_MAX_TOKENS:
+            y = ops.tok_attention(qkv, b, n, h)
+        else:
+            q, k, v = qkv.view(b, n, 3, h, c // h).permute(2, 0, 3, 1, 4).unbind(0)
+            y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(m, c)
         if own["proj"]:
             ops.tok_linear(y, blk.attn.proj.weight, blk.attn.proj.bias, epilogue=ops.TOK_EPI_RESID, residual=x, gamma=g1, out=x)
         else:

@@ -327,6 +327,195 @@ __global__ void __launch_bounds__(256) k_tok_pack(const float* __restrict__ w, i
   }
 }
 
+// ---- attention of a ViT block (dinov2 Attention.forward: softmax(q k^T / sqrt(64)) v per image and head) on the [M][3 * heads * 64] output of the QKV
+// product, token-major in and out -- no head-major copies, one launch.  PyTorch's scaled_dot_product_attention (aotriton attn_fwd) takes 27 us for one
+// image and 43 us for sixteen: 12 launches of it are a third of the ViT at one image.
+// One workgroup = one (image, head, group of 128 queries); 4 waves, a wave owns 32 queries against ALL keys (T <= 288 = 9 key tiles):
+//   S^T[key][query] = sum_d K[key][d] Q[query][d]: keys are MFMA rows, queries MFMA columns, so a lane owns ONE query (+ its partner lane 32 further the
+//   other half of that query's keys): the softmax over keys is a reduction over the lane's own 144 registers and one lane exchange -- no LDS, no barrier;
+//   the probabilities never leave the registers: the accumulator layout of S^T is, up to a permutation of the keys inside a tile, the B-operand layout
+//   of O^T[d][query] = sum_key V^T[d][key] P^T[key][query]; the permutation is applied to the keys of V's fragments instead (two 8-byte reads).
+// K (as [key][d]) and V (transposed, [d][key]) of the head are staged once per workgroup as two scaled fp16 planes each (one scale per head: its largest
+// magnitude), Q stays in registers (one scale per query, the 1/8 folded in).  Arithmetic as everywhere: h + l planes, three cross terms, fp32 accumulation;
+// exp2 on fp32 logits; P as h + l planes of p * 2^14.
+constexpr int kAtD = 64;                      // head dimension
+constexpr int kAtKT = 9;                      // key tiles of 32: tokens <= 288
+constexpr int kAtKRow = 2 * kAtD * 2 + 16;    // LDS row of a key: plane h 128 B | plane l 128 B | 16 B (17 slots of 16 B: odd)
+constexpr int kAtVPlane = kAtKT * 32 * 2;     // bytes of one plane of a V^T row: 288 keys
+constexpr int kAtVRow = 2 * kAtVPlane + 8;    // 1160 B: 290 dwords, 290 mod 64 = 34: the 32 rows of a fragment read start on 32 distinct even banks
+
+struct AttnArgs {
+  const float* qkv;      // [images * tokens][ldq]: q | k | v, each heads * 64 wide
+  float* y;              // [images * tokens][ldy]
+  int64_t ldq, ldy;
+  int tokens, heads;
+};
+
+__global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
+  __shared__ __attribute__((aligned(16))) char Kp[kAtKT * 32 * kAtKRow];
+  __shared__ __attribute__((aligned(16))) char Vt[kAtD * kAtVRow];
+  __shared__ float wmax[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img = (int)blockIdx.x / A.heads, head = (int)blockIdx.x - img * A.heads;
+  const int T = A.tokens, width = A.heads * kAtD;
+  const float* base = A.qkv + (int64_t)img * T * A.ldq + head * kAtD;      // q of token 0; k at + width, v at + 2 width
+
+  // ---- stage K and V^T: thread = (key t / 16 + 16 i, 4 consecutive d) ------------------------------------------------------------------------------------
+  {
+    constexpr int NI = (kAtKT * 32 + 15) / 16;      // 18 passes of 16 keys
+    const int c4 = (tid & 15) * 4, k0 = tid >> 4;
+    float4 kv[NI], vv[NI];
+    float mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = k0 + 16 * i;
+      if (key < T) {
+        const float* p = base + (int64_t)key * A.ldq + width + c4;
+        kv[i] = *reinterpret_cast<const float4*>(p);
+        vv[i] = *reinterpret_cast<const float4*>(p + width);
+      } else {
+        kv[i] = float4{0.f, 0.f, 0.f, 0.f};
+        vv[i] = float4{0.f, 0.f, 0.f, 0.f};
+      }
+      mk = fmaxf(fmaxf(mk, fmaxf(fabsf(kv[i].x), fabsf(kv[i].y))), fmaxf(fabsf(kv[i].z), fabsf(kv[i].w)));
+      mv = fmaxf(fmaxf(mv, fmaxf(fabsf(vv[i].x), fabsf(vv[i].y))), fmaxf(fabsf(vv[i].z), fabsf(vv[i].w)));
+    }
+    mk = sdg_wave_max(mk);
+    mv = sdg_wave_max(mv);
+    if (lane == 0) { wmax[0][wave] = mk; wmax[1][wave] = mv; }
+    __syncthreads();
+    mk = fmaxf(fmaxf(wmax[0][0], wmax[0][1]), fmaxf(wmax[0][2], wmax[0][3]));
+    mv = fmaxf(fmaxf(wmax[1][0], wmax[1][1]), fmaxf(wmax[1][2], wmax[1][3]));
+    const float sk = f3_scale(mk), sv = f3_scale(mv);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = k0 + 16 * i;
+      if (key >= kAtKT * 32) continue;
+      const float ke[4] = {kv[i].x * sk, kv[i].y * sk, kv[i].z * sk, kv[i].w * sk};
+      const float ve[4] = {vv[i].x * sv, vv[i].y * sv, vv[i].z * sv, vv[i].w * sv};
+      f16x4_t kh, kl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 hh = (_Float16)ke[j];
+        kh[j] = hh;
+        kl[j] = (_Float16)(ke[j] - (float)hh);
+        const _Float16 vh = (_Float16)ve[j];
+        *reinterpret_cast<_Float16*>(Vt + (c4 + j) * kAtVRow + key * 2) = vh;
+        *reinterpret_cast<_Float16*>(Vt + (c4 + j) * kAtVRow + kAtVPlane + key * 2) = (_Float16)(ve[j] - (float)vh);
+      }
+      *reinterpret_cast<f16x4_t*>(Kp + key * kAtKRow + c4 * 2) = kh;
+      *reinterpret_cast<f16x4_t*>(Kp + key * kAtKRow + 2 * kAtD + c4 * 2) = kl;
+    }
+    __syncthreads();      // (the reciprocal scales are recomputed from mk / mv below: exact powers of two)
+    // ---- this wave's 32 queries -----------------------------------------------------------------------------------------------------------------------------
+    const int q0 = ((int)blockIdx.y * 4 + wave) * 32;
+    if (q0 >= T) return;
+    const int ql = lane & 31, half = lane >> 5;
+    const int q = q0 + ql < T ? q0 + ql : T - 1;                                  // queries beyond T: a valid row is computed, nothing is stored
+    const float* qp = base + (int64_t)q * A.ldq + 8 * half;
+    float4 qa[4][2];
+    float mq = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      qa[s4][0] = *reinterpret_cast<const float4*>(qp + 16 * s4);
+      qa[s4][1] = *reinterpret_cast<const float4*>(qp + 16 * s4 + 4);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) mq = fmaxf(fmaxf(mq, fmaxf(fabsf(qa[s4][u].x), fabsf(qa[s4][u].y))), fmaxf(fabsf(qa[s4][u].z), fabsf(qa[s4][u].w)));
+    }
+    mq = fmaxf(mq, __shfl_xor(mq, 32, 64));
+    const float sq = f3_scale(mq);
+    f16x8_t qh[4], qlo[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float e[8] = {qa[s4][0].x, qa[s4][0].y, qa[s4][0].z, qa[s4][0].w, qa[s4][1].x, qa[s4][1].y, qa[s4][1].z, qa[s4][1].w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = e[j] * sq;
+        const _Float16 hh = (_Float16)x;
+        qh[s4][j] = hh;
+        qlo[s4][j] = (_Float16)(x - (float)hh);
+      }
+    }
+    // ---- S^T = K Q^T ------------------------------------------------------------------------------------------------------------------------------------------
+    f32x16 acc[kAtKT];
+    const char* kfr = Kp + ql * kAtKRow + half * 16;
+#pragma unroll
+    for (int kt = 0; kt < kAtKT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const f16x8_t kh = *reinterpret_cast<const f16x8_t*>(kfr + kt * 32 * kAtKRow + s4 * 32);
+        const f16x8_t kl = *reinterpret_cast<const f16x8_t*>(kfr + kt * 32 * kAtKRow + 2 * kAtD + s4 * 32);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s4], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qlo[s4], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s4], acc[kt], 0, 0, 0);
+      }
+    }
+    // ---- softmax over the keys of this lane's query: logits * log2(e) / 8, exp2 --------------------------------------------------------------------------------
+    const float f = f3_inv_scale(mq) * f3_inv_scale(mk) * (0.125f * 1.4426950408889634f);
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int kt = 0; kt < kAtKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+        const float t = key < T ? acc[kt][i] * f : -__builtin_inff();
+        acc[kt][i] = t;
+        mx = fmaxf(mx, t);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < kAtKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(acc[kt][i] - mx);
+        acc[kt][i] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    // ---- O^T = V^T P^T: the lane's probabilities of a key tile are the B operand as they lie (keys (e & 3) + 8 (e >> 2) + 16 s2 + 4 half, e = 0..7) ---------
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    const char* vfr = Vt + ql * kAtVRow + half * 8;
+#pragma unroll
+    for (int kt = 0; kt < kAtKT; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8_t ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = acc[kt][8 * s2 + e] * 16384.f;
+          const _Float16 hh = (_Float16)x;
+          ph[e] = hh;
+          pl[e] = (_Float16)(x - (float)hh);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vp = vfr + dt * 32 * kAtVRow + (kt * 32 + 16 * s2) * 2;
+          const f16x4_t h0 = *reinterpret_cast<const f16x4_t*>(vp), h1 = *reinterpret_cast<const f16x4_t*>(vp + 16);
+          const f16x4_t l0 = *reinterpret_cast<const f16x4_t*>(vp + kAtVPlane), l1 = *reinterpret_cast<const f16x4_t*>(vp + kAtVPlane + 16);
+          const f16x8_t vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          const f16x8_t vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[dt], 0, 0, 0);
+        }
+      }
+    if (q0 + ql < T) {
+      const float g = f3_inv_scale(mv) * (1.f / 16384.f) / sum;
+      float* yp = A.y + ((int64_t)img * T + q0 + ql) * A.ldy + head * kAtD + 4 * half;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float4*>(yp + dt * 32 + 8 * rg) = float4{o[dt][4 * rg] * g, o[dt][4 * rg + 1] * g, o[dt][4 * rg + 2] * g, o[dt][4 * rg + 3] * g};
+    }
+  }
+}
+
 // a22's convolutions as GEMMs (camera_direction_network.py:29-36: valid k x k convolutions of the 16 x 16 feature map): the A matrix of a whole batch in
 // ONE launch from a feature map with FREE strides, so the previous layer's GEMM output [B * ho * wo][C] is read where it lies (no permute copy).
 // PyTorch's unfold launches one im2col kernel per IMAGE (64 launches of ~8 us for 16 images and four layers) and needed a transposing copy behind it.
@@ -423,6 +612,18 @@ int sixdgs_tok_pack(const float* w, int n, int k, int64_t ldw, void* planes, flo
   SDG_CHECK_ARG(w && planes && inv_scale && n > 0 && (n % 128) == 0 && k > 0 && (k % kCK) == 0 && ldw >= k);
   SDG_CHECK_ARG(((uintptr_t)planes % 16) == 0);
   hipLaunchKernelGGL(k_tok_pack, dim3((unsigned)(n / 32)), dim3(256), 0, sdg_stream(stream), w, k, ldw, static_cast<char*>(planes), inv_scale);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+int sixdgs_tok_attention(const float* qkv, int64_t ldq, int images, int tokens, int heads, float* y, int64_t ldy, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(images >= 0 && tokens > 0 && heads > 0);
+  if (images == 0) return 0;
+  if (tokens > kAtKT * 32) return SIXDGS_E_UNSUPPORTED;                              // one wave holds a query's logits against ALL keys in registers
+  SDG_CHECK_ARG(qkv && y && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)y % 16) == 0 && (ldq % 4) == 0 && ldq >= 3 * (int64_t)heads * kAtD && (ldy % 4) == 0 &&
+                ldy >= (int64_t)heads * kAtD && (int64_t)images * heads <= 0x7fffffffLL);
+  AttnArgs A = {qkv, y, ldq, ldy, tokens, heads};
+  hipLaunchKernelGGL(k_tok_attn, dim3((unsigned)(images * heads), (unsigned)sdg_cdiv(tokens, 128)), dim3(256), 0, sdg_stream(stream), A);
   SDG_LAUNCH_OK();
   return 0;
 }

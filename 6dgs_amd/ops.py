@@ -364,6 +364,22 @@ def linear(x, w, b=None, relu: bool = False, mma_mode: Optional[int] = None, spl
     return y
 
 
+TOK_ATTENTION_MAX_TOKENS = 288
+
+
+@_on_device
+def tok_attention(qkv: torch.Tensor, images: int, tokens: int, heads: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / 8) v per image and head on the QKV product's output [images * tokens, 3 * heads * 64] as it lies (q | k | v, head h at columns
+    h * 64 of each) -> [images * tokens, heads * 64], token-major (sixdgs_tok_attention; head dimension 64, tokens <= 288)."""
+    qkv = qkv.detach()
+    if qkv.dtype != torch.float32 or qkv.dim() != 2 or qkv.shape[0] != images * tokens or qkv.shape[1] != 3 * heads * 64 or qkv.stride(1) != 1:
+        raise RuntimeError(f"6dgs_amd: tok_attention needs float32 qkv [{images * tokens}, {3 * heads * 64}], got {qkv.dtype} {tuple(qkv.shape)}")
+    _need_gpu(qkv)
+    y = out if out is not None else torch.empty(images * tokens, heads * 64, device=qkv.device)
+    check(_lib.load().sixdgs_tok_attention(_p(qkv), qkv.stride(0), int(images), int(tokens), int(heads), _p(y), y.stride(0), _stream()), "tok_attention")
+    return y
+
+
 @_on_device
 def im2col(x: torch.Tensor, k: int, taps_major: bool = False) -> torch.Tensor:
     """[B, C, H, W] fp32 (ANY strides: a permuted view of a [B*H*W, C] GEMM output is read in place) -> the A matrix [B*ho*wo, C*k*k] of the valid

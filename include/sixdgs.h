@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion), sixdgs_im2col, sixdgs_u8_to_planar; the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion), sixdgs_tok_attention, sixdgs_im2col, sixdgs_u8_to_planar; the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -251,6 +251,11 @@ int sixdgs_tok_pack(const float* w /*[n][ldw]*/, int n, int k, int64_t ldw, void
 int sixdgs_tok_linear(const float* x, int64_t m, int k, int64_t ldx, int a_mode, const float* ln_weight, const float* ln_bias, float ln_eps,
                       const void* w_planes, const float* w_inv_scale, const float* bias /*[n] or NULL*/, int n, int epilogue, const float* residual,
                       int64_t ldr, const float* gamma, float* y, int64_t ldy, sixdgs_stream_t stream);
+
+/* The attention of a ViT block (dinov2 Attention.forward: softmax(q k^T / sqrt(64)) v per image and head) on the QKV product's output as it lies:
+ * qkv [images * tokens][ldq] = q | k | v, each heads * 64 wide, head h at columns h * 64; y [images * tokens][ldy], head h at columns h * 64 (what
+ * attn.proj reads).  Head dimension 64, tokens <= 288 (SIXDGS_E_UNSUPPORTED beyond: the caller keeps its own attention); fp32-class results. */
+int sixdgs_tok_attention(const float* qkv, int64_t ldq, int images, int tokens, int heads, float* y, int64_t ldy, sixdgs_stream_t stream);
 
 /* a22 (camera_direction_network.py:29-36, the valid k x k convolutions of the camera-up CNN) as GEMMs: the im2col matrix of a whole batch in one
  * launch.  a [batch * ho * wo][channels * k * k] (ho = height - k + 1, wo = width - k + 1): row (b, oy, ox); column (c, ky, kx) -- the order of

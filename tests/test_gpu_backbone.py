@@ -221,6 +221,33 @@ def test_tok_linear_prologues_and_epilogues(ops):
         ops.tok_linear(R(10, 384), R(64, 384))           # N not a multiple of 128
 
 
+def test_tok_attention_against_fp64(ops):
+    """sixdgs_tok_attention (softmax(q k^T / 8) v per image and head on the [M, 1152] QKV matrix as it lies) against the fp64 evaluation of
+    F.scaled_dot_product_attention on the permuted views the module uses: 257 tokens (the ViT's), a short and the longest supported sequence, logits of
+    very different spreads (flat and peaked softmax), q / k / v of different magnitudes; <= 2e-6 of the largest output, and against PyTorch's own fp32
+    kernel."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(17)
+    for images, tokens, heads, qs, ks, vs in ((1, 257, 6, 1.0, 1.0, 1.0), (3, 257, 6, 6.0, 3.0, 0.01), (2, 40, 2, 0.05, 0.05, 30.0), (1, 288, 1, 2.0, 2.0, 1.0),
+                                              (16, 257, 6, 1.0, 2.0, 1.0)):
+        c = heads * 64
+        qkv = torch.randn(images * tokens, 3 * c, generator=g)
+        qkv[:, :c] *= qs
+        qkv[:, c:2 * c] *= ks
+        qkv[:, 2 * c:] *= vs
+        qkv = qkv.cuda()
+        q, k, v = qkv.double().view(images, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4).unbind(0)
+        ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(images * tokens, c)
+        y = ops.tok_attention(qkv, images, tokens, heads)
+        err = float((y.double() - ref).abs().max() / ref.abs().max())
+        q32, k32, v32 = qkv.view(images, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4).unbind(0)
+        t32 = F.scaled_dot_product_attention(q32, k32, v32).transpose(1, 2).reshape(images * tokens, c)
+        terr = float((t32.double() - ref).abs().max() / ref.abs().max())
+        assert err < max(2e-6, 4 * terr), (images, tokens, heads, err, terr)
+    with pytest.raises(RuntimeError):
+        ops.tok_attention(torch.zeros(300, 192, device="cuda"), 1, 300, 1)            # more tokens than a wave holds logits for
+
+
 def test_im2col_and_u8_to_planar_are_exact(ops):
     """sixdgs_im2col against torch.nn.functional.unfold (the A matrix of the camera-up CNN's valid convolutions: same values, same column order) on
     a contiguous map and on a permuted view of a [B*H*W, C] matrix (how the previous layer's GEMM output is read in place); sixdgs_u8_to_planar

@@ -79,10 +79,15 @@ def main():
             err = float((own().double() - r).abs().max() / r.abs().max())
             tl, to = tl + a, to + b
             print(f"| {images} | {m} | {name} | {a:.1f} | {b:.1f} | {b / a:.2f} | {fl / a / 1e6:.1f} | {fl / b / 1e6:.1f} | {err:.1e} |")
-        qkv = torch.randn(3, images, heads, tokens, 64, device=dev)
-        at = graph_us(lambda: F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]))
+        qkv = torch.randn(m, 1152, device=dev)
+        q_, k_, v_ = qkv.view(images, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4).unbind(0)
+        at = graph_us(lambda: F.scaled_dot_product_attention(q_, k_, v_).transpose(1, 2).reshape(m, 384))
+        ao = graph_us(lambda: ops.tok_attention(qkv, images, tokens, heads))
+        qd, kd, vd = qkv.double().view(images, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4).unbind(0)
+        r = F.scaled_dot_product_attention(qd, kd, vd).transpose(1, 2).reshape(m, 384)
+        aerr = float((ops.tok_attention(qkv, images, tokens, heads).double() - r).abs().max() / r.abs().max())
         print(f"| {images} | {m} | the four dense stages of a block | {tl:.1f} | {to:.1f} | {to / tl:.2f} | | | |")
-        print(f"| {images} | {m} | attention (F.scaled_dot_product_attention, both forms) | {at:.1f} | {at:.1f} | | | | |")
+        print(f"| {images} | {m} | attention (F.scaled_dot_product_attention on strided views vs sixdgs_tok_attention) | {at:.1f} | {ao:.1f} | {ao / at:.2f} | | | {aerr:.1e} |")
     # the whole ViT-S/14 forward as a hipGraph, blocks fused (five launches) and not
     bb = importlib.import_module("6dgs_amd.backbone")
     vit = bb.ViTS14().eval().cuda()
