@@ -148,7 +148,7 @@ class ViTS14(torch.nn.Module):
         t = self.patch_embed(x)
         t = torch.cat([self.cls_token.expand(b, -1, -1), t], dim=1) + self._pos(x.shape[-1] // self.patch_size)
         if fused_blocks_usable(self, t):
-            t = fused_blocks(self.blocks, t)
+            t = fused_blocks(self.blocks, t, owned=True)          # (t is this function's own temporary: the blocks may update it in place)
         else:
             for blk in self.blocks:
                 t = blk(t)
@@ -176,7 +176,7 @@ def fused_blocks_usable(vit, t) -> bool:
         return False
 
 
-def fused_blocks(blocks, t: torch.Tensor) -> torch.Tensor:
+def fused_blocks(blocks, t: torch.Tensor, owned: bool = False) -> torch.Tensor:
     """x + ls1(attn(norm1(x))), then x + ls2(mlp(norm2(x))) for every block (_Block.forward; dinov2's NestedTensorBlock at inference) as FIVE launches:
          LayerNorm + QKV product + bias                              (sixdgs_tok_linear: A_LAYERNORM, EPI_BIAS)
          attention on that [M, 1152] matrix as it lies, token-major out  (sixdgs_tok_attention; F.scaled_dot_product_attention on strided views otherwise)
@@ -192,7 +192,7 @@ def fused_blocks(blocks, t: torch.Tensor) -> torch.Tensor:
     force = os.environ.get("SIXDGS_VIT_FUSED", "1") == "all"
     own = {k: force or m >= v for k, v in FUSED_MIN_ROWS.items()}
     x = t.reshape(m, c).contiguous()
-    if x.data_ptr() == t.data_ptr():
+    if x.data_ptr() == t.data_ptr() and not owned:
         x = x.clone()          # the residual stream is updated in place: never the caller's tensor
     one = None
     for blk in blocks:

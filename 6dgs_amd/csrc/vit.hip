@@ -407,10 +407,11 @@ __global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
       *reinterpret_cast<f16x4_t*>(Kp + key * kAtKRow + 2 * kAtD + c4 * 2) = kl;
     }
     __syncthreads();      // (the reciprocal scales are recomputed from mk / mv below: exact powers of two)
-    // ---- this wave's 32 queries -----------------------------------------------------------------------------------------------------------------------------
-    const int q0 = ((int)blockIdx.y * 4 + wave) * 32;
-    if (q0 >= T) return;
+    // ---- this wave's query tiles of 32: tile (blockIdx.y * 4 + wave), then every (4 gridDim.y)-th (with 3 groups and 257 tokens one tile per wave; with
+    //      2 groups -- chosen by the launcher when 3 would need a second round of workgroups -- one wave of the image takes the ninth tile too) -----------
     const int ql = lane & 31, half = lane >> 5;
+#pragma unroll 1
+    for (int q0 = ((int)blockIdx.y * 4 + wave) * 32; q0 < T; q0 += 128 * (int)gridDim.y) {
     const int q = q0 + ql < T ? q0 + ql : T - 1;                                  // queries beyond T: a valid row is computed, nothing is stored
     const float* qp = base + (int64_t)q * A.ldq + 8 * half;
     float4 qa[4][2];
@@ -438,7 +439,11 @@ __global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
     }
     // ---- S^T = K Q^T ------------------------------------------------------------------------------------------------------------------------------------------
     f32x16 acc[kAtKT];
-    const char* kfr = Kp + ql * kAtKRow + half * 16;
+    // (fragment addresses from an opaque copy of the lane index, formed HERE: K and V^T do not change between the query tiles of a wave, and as loop
+    //  invariants every one of their ~200 fragment reads was hoisted out of the tile loop and spilled -- 434 registers)
+    unsigned lo_ = (unsigned)lane;
+    asm volatile("" : "+v"(lo_));
+    const char* kfr = Kp + (lo_ & 31u) * kAtKRow + (lo_ >> 5) * 16;
 #pragma unroll
     for (int kt = 0; kt < kAtKT; ++kt) {
 #pragma unroll
@@ -455,15 +460,26 @@ __global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
     // ---- softmax over the keys of this lane's query: logits * log2(e) / 8, exp2 --------------------------------------------------------------------------------
     const float f = f3_inv_scale(mq) * f3_inv_scale(mk) * (0.125f * 1.4426950408889634f);
     float mx = -__builtin_inff();
+    const int half_o = (int)(lo_ >> 5);      // (opaque: as invariants of the tile loop the 144 key masks were hoisted into 288 scalar registers and spilled)
 #pragma unroll
-    for (int kt = 0; kt < kAtKT; ++kt)
+    for (int kt = 0; kt < kAtKT; ++kt) {
+      if ((kt + 1) * 32 <= T) {              // a full key tile (wave-uniform): no masks
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-        const float t = key < T ? acc[kt][i] * f : -__builtin_inff();
-        acc[kt][i] = t;
-        mx = fmaxf(mx, t);
+        for (int i = 0; i < 16; ++i) {
+          const float t = acc[kt][i] * f;
+          acc[kt][i] = t;
+          mx = fmaxf(mx, t);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half_o;
+          const float t = key < T ? acc[kt][i] * f : -__builtin_inff();
+          acc[kt][i] = t;
+          mx = fmaxf(mx, t);
+        }
       }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
@@ -479,7 +495,7 @@ __global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    const char* vfr = Vt + ql * kAtVRow + half * 8;
+    const char* vfr = Vt + (lo_ & 31u) * kAtVRow + (lo_ >> 5) * 8;
 #pragma unroll
     for (int kt = 0; kt < kAtKT; ++kt)
 #pragma unroll
@@ -513,6 +529,7 @@ __global__ void __launch_bounds__(256) k_tok_attn(AttnArgs A) {
         for (int rg = 0; rg < 4; ++rg)
           *reinterpret_cast<float4*>(yp + dt * 32 + 8 * rg) = float4{o[dt][4 * rg] * g, o[dt][4 * rg + 1] * g, o[dt][4 * rg + 2] * g, o[dt][4 * rg + 3] * g};
     }
+    }      // query tiles of this wave
   }
 }
 
@@ -623,7 +640,17 @@ int sixdgs_tok_attention(const float* qkv, int64_t ldq, int images, int tokens, 
   SDG_CHECK_ARG(qkv && y && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)y % 16) == 0 && (ldq % 4) == 0 && ldq >= 3 * (int64_t)heads * kAtD && (ldy % 4) == 0 &&
                 ldy >= (int64_t)heads * kAtD && (int64_t)images * heads <= 0x7fffffffLL);
   AttnArgs A = {qkv, y, ldq, ldy, tokens, heads};
-  hipLaunchKernelGGL(k_tok_attn, dim3((unsigned)(images * heads), (unsigned)sdg_cdiv(tokens, 128)), dim3(256), 0, sdg_stream(stream), A);
+  // groups of 4 query tiles per (image, head): as many as the tokens need while every workgroup finds a compute unit at once (152 KB of LDS: one per unit);
+  // beyond that one group fewer -- a wave then walks a second tile instead of a second round of workgroups staging K and V again
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  int groups = (int)sdg_cdiv(tokens, 128);
+  while (groups > 1 && (int64_t)images * heads * groups > cus) --groups;
+  hipLaunchKernelGGL(k_tok_attn, dim3((unsigned)(images * heads), (unsigned)groups), dim3(256), 0, sdg_stream(stream), A);
   SDG_LAUNCH_OK();
   return 0;
 }
