@@ -757,12 +757,22 @@ int dense_chain(const float* ori, const float* dir, const float* rgb, int64_t m,
                ok = o4 + (size_t)384 * 16 * kSlabB, o4k = ok + (size_t)384 * 12 * kSlabB;
   hipLaunchKernelGGL(k_ray_encode_planes, dim3((unsigned)sdg_cdiv(m, kEncRays)), dim3(256), 0, s, ori, dir, rgb, m, xp, xs, cm);
   int st;
+#ifdef SDG_DENSE_PROF      // developer build: stop behind layer n, so that the cycle stamps (one set, overwritten by every launch) are that layer's
+  const char* stop_e = getenv("SIXDGS_DENSE_PROF_LAYER");
+  const int stop_at = stop_e ? atoi(stop_e) : 0;
+#define SDG_PROF_STOP(N) if (stop_at == (N)) return 0;
+#else
+#define SDG_PROF_STOP(N)
+#endif
   DenseArgs l1 = {wplanes + o1, w->m1, w->b1, xp, xs, nullptr, nullptr, 5, 0, 2, 0, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l1, s))) return st;
+  SDG_PROF_STOP(1)
   DenseArgs l2 = {wplanes + o2, w->m2, w->b2, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 512, hp2, sb, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l2, s))) return st;
+  SDG_PROF_STOP(2)
   DenseArgs l3 = {wplanes + o3, w->m3, w->b3, hp2, sb, xp, xs, 16, 5, 4, 2, m, 512, hp1, sa, nullptr, 0, 1, nullptr, cm, cm, nullptr};
   if ((st = launch_dense(l3, s))) return st;
+  SDG_PROF_STOP(3)
   if (dense_fold_kproj()) {
     // layer 4 and k_proj as ONE layer on h3: fp32 keys, or (kplanes) the scorer's key planes, tile scales and key-norm maximum
     DenseArgs l4k = {wplanes + o4k, w->m4k, w->b4k, hp1, sa, nullptr, nullptr, 16, 0, 4, 0, m, 384, kplanes, nullptr, kplanes ? nullptr : kdst, SIXDGS_D, 0,

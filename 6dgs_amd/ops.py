@@ -444,11 +444,10 @@ class TokWeights:
             return hit[3]
         if w.dim() != 2:
             raise RuntimeError(f"6dgs_amd: a dense layer's weight is [n, k], got {tuple(w.shape)}")
+        for k_ in [k_ for k_, v_ in cls._cache.items() if v_[0]() is None]:      # packs of tensors that are gone (an evaluation sweep loads a module per scene)
+            del cls._cache[k_]
         with torch.cuda.device(w.device):
             tw = cls(w)
-        if len(cls._cache) > 512:
-            for k_ in [k_ for k_, v_ in cls._cache.items() if v_[0]() is None]:
-                del cls._cache[k_]
         cls._cache[key] = (weakref.ref(w), w._version, w.data_ptr(), tw)
         return tw
 
