@@ -32,3 +32,43 @@ def test_arena_serves_one_module_at_a_time(ops):
     import gc
     gc.collect()
     a.reset(m1)
+
+
+def test_taps_major_weight_matches_the_patch_order_of_im2col():
+    """camera_direction_network._taps_major_weight: conv.weight with its columns in (kh, kw, c) order, the order ops.im2col(taps_major=True) lays the
+    patches out in -- checked on the CPU against F.conv2d with the patch matrix rebuilt from F.unfold (the GPU test checks the kernel against the same
+    reordering of unfold)."""
+    import importlib
+    import torch
+    import torch.nn.functional as F
+    cdn = importlib.import_module("6dgs_amd.camera_direction_network")
+    torch.manual_seed(0)
+    net = cdn.CameraDirectionPredictor(image_feature_channel=6, image_size=(16, 16))
+    conv = net.dim_reducer1[0]
+    x = torch.randn(2, 6, 9, 8)
+    k = conv.kernel_size[0]
+    ho, wo = x.shape[2] - k + 1, x.shape[3] - k + 1
+    cols = F.unfold(x, k)                                                                 # [B, C*k*k, L], rows (c, kh, kw)
+    tm = cols.view(2, 6, k * k, ho * wo).permute(0, 3, 2, 1).reshape(2 * ho * wo, k * k * 6)      # rows (b, oy, ox), columns (kh, kw, c)
+    wt = net._taps_major_weight(conv)
+    assert wt.shape == (conv.out_channels, k * k * 6) and net._taps_major_weight(conv) is wt      # cached per parameter version
+    y = (tm @ wt.t() + conv.bias).view(2, ho, wo, -1).permute(0, 3, 1, 2)
+    assert torch.allclose(y, conv(x), atol=1e-5)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    assert net._taps_major_weight(conv) is not wt                                         # a changed parameter is permuted again
+
+
+def test_fused_vit_blocks_are_a_gpu_inference_path_only():
+    """backbone.fused_blocks_usable: CPU tensors, gradient mode and SIXDGS_VIT_FUSED=0 keep PyTorch's blocks; every stage has a row-count threshold."""
+    import importlib
+    import torch
+    bb = importlib.import_module("6dgs_amd.backbone")
+    vit = bb.ViTS14(depth=1).eval()
+    t = torch.zeros(1, 257, 384)
+    with torch.no_grad():
+        assert not bb.fused_blocks_usable(vit, t)
+    assert set(bb.FUSED_MIN_ROWS) == {"qkv", "attn", "proj", "fc1", "fc2"} and all(v >= 0 for v in bb.FUSED_MIN_ROWS.values())
+    with torch.no_grad():
+        out = vit.forward_features(torch.zeros(1, 3, 224, 224))
+    assert out["x_norm_patchtokens"].shape == (1, 256, 384)
