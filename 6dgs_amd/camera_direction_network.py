@@ -50,6 +50,8 @@ class CameraDirectionPredictor(torch.nn.Module):
         if hit is not None and hit[0] == (w._version, w.data_ptr(), str(w.device)):
             return hit[1]
         wt = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+        if wt.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(wt.device).synchronize()      # kept for the life of the weight and possibly read next from another stream: finish it here, once
         cache[id(conv)] = ((w._version, w.data_ptr(), str(w.device)), wt)
         return wt
 

@@ -434,6 +434,10 @@ class TokWeights:
         self.planes = torch.empty(lib.sixdgs_tok_pack_bytes(self.n, self.k), dtype=torch.uint8, device=w.device)
         self.inv_scale = torch.empty(self.n, dtype=torch.float32, device=w.device)
         check(lib.sixdgs_tok_pack(_p(w), self.n, self.k, w.stride(0), _p(self.planes), _p(self.inv_scale), _stream()), "tok_pack")
+        # the pack is kept for the life of the weight and may be read next from ANOTHER stream (a pipeline's image stream, a graph captured elsewhere):
+        # finish it here, once per weight (48 x ~25 us for a ViT-S/14), instead of carrying an event through every later call
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(w.device).synchronize()
 
     @classmethod
     def of(cls, w: torch.Tensor) -> "TokWeights":
