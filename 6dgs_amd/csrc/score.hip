@@ -1537,7 +1537,8 @@ constexpr int64_t kTopkSmallMax = 1 << 17;
 __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ scores, int64_t stride, int n, int topk, int k_eff,
                                                       int64_t* __restrict__ idx, float* __restrict__ val, const int* __restrict__ only) {
   __shared__ unsigned hist[256];
-  __shared__ unsigned sel[2];              // prefix of the k-th largest key decided so far, how many are still needed among the keys matching it
+  __shared__ unsigned sel[3];              // prefix of the k-th largest key decided so far, how many are still needed among the keys matching it, how many match it
+  __shared__ unsigned slot;                // next free position of the unordered gather
   __shared__ unsigned sk[1024];
   __shared__ long long si[1024];
   __shared__ int wc[2][16];
@@ -1556,22 +1557,33 @@ __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ s
       // The first passes see (nearly) ONE digit for every element -- scores of one image share their sign and leading exponent bits -- and 64 lanes
       // adding to one LDS word serialise (the first build spent 160 us per call on exactly that, profiles/r04_bench_headline_kernel_trace.md): the lanes
       // that share the first active lane's digit are counted with a ballot and added once; the others (later passes: few, scattered) add for themselves.
-      for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + t;
-        unsigned key = 0u;
-        bool act = false;
-        if (i < n) {
-          key = score_key(s[i]);
-          act = (key & hi_mask) == prefix;
+      // (eight values per thread requested before the first is looked at: with one load per iteration the workgroup waited ~0.7 us for each of 122 -- 85 us per pass)
+      for (int c0 = 0; c0 < n; c0 += 8 * 1024) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = c0 + u * 1024 + t;
+          v8[u] = i < n ? s[i] : 0.f;
         }
-        const unsigned bin = (key >> shift) & 255u;
-        const unsigned long long m = __ballot(act);
-        if (m != 0ull) {
-          const int leader = __ffsll((long long)m) - 1;
-          const unsigned lb = (unsigned)__shfl((int)bin, leader);
-          const unsigned long long same = __ballot(act && bin == lb);
-          if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
-          else if (act && bin != lb) atomicAdd(&hist[bin], 1u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = c0 + u * 1024 + t;
+          if (c0 + u * 1024 >= n) break;      // (uniform)
+          unsigned key = 0u;
+          bool act = false;
+          if (i < n) {
+            key = score_key(v8[u]);
+            act = (key & hi_mask) == prefix;
+          }
+          const unsigned bin = (key >> shift) & 255u;
+          const unsigned long long m = __ballot(act);
+          if (m != 0ull) {
+            const int leader = __ffsll((long long)m) - 1;
+            const unsigned lb = (unsigned)__shfl((int)bin, leader);
+            const unsigned long long same = __ballot(act && bin == lb);
+            if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+            else if (act && bin != lb) atomicAdd(&hist[bin], 1u);
+          }
         }
       }
       __syncthreads();
@@ -1586,7 +1598,7 @@ __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ s
           bool found = false;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (!found && acc + c[j] >= remain) { digit = (unsigned)(255 - (4 * t + j)); rem = remain - acc; found = true; }
+            if (!found && acc + c[j] >= remain) { digit = (unsigned)(255 - (4 * t + j)); rem = remain - acc; found = true; sel[2] = c[j]; }
             acc += c[j];
           }
           sel[0] = prefix | (digit << shift);
@@ -1597,8 +1609,46 @@ __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ s
       prefix = sel[0];
       remain = sel[1];
     }
+    const unsigned thr = prefix, n_greater = (unsigned)k_eff - remain, n_equal = sel[2];      // (after the last pass the bin count is the number of keys EQUAL to the threshold)
+    if (n_greater + n_equal <= 1024u) {
+      // Everything at or above the threshold fits the sort buffer (the usual case: k keys above a threshold that few share): gather it in ANY order -- one
+      // sweep, a wave-aggregated atomic for the positions, no barrier -- and let the sort below put it into (key descending, index ascending) order; the first
+      // k_eff entries are then the same as the ordered gather's (which pays two workgroup barriers per 1024 values for an order the sort establishes anyway).
+      if (t == 0) slot = 0u;
+      __syncthreads();
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int c0 = 0; c0 < n; c0 += 8 * 1024) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = c0 + u * 1024 + t;
+          v8[u] = i < n ? s[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = c0 + u * 1024 + t;
+          if (c0 + u * 1024 >= n) break;      // (uniform)
+          unsigned key = 0u;
+          bool hit = false;
+          if (i < n) {
+            key = score_key(v8[u]);
+            hit = key >= thr;
+          }
+          const unsigned long long m = __ballot(hit);
+          if (m != 0ull) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0u;
+            if (lane == leader) base = atomicAdd(&slot, (unsigned)__popcll(m));
+            base = (unsigned)__shfl((int)base, leader);
+            if (hit) {
+              const unsigned pos = base + (unsigned)__popcll(m & below);
+              if (pos < 1024u) { sk[pos] = key; si[pos] = (long long)i; }
+            }
+          }
+        }
+      }
+    } else {
     // ordered gather: keys above the threshold at their running rank, keys equal to it (in index order) behind them while `remain` lasts
-    const unsigned thr = prefix, n_greater = (unsigned)k_eff - remain;
     unsigned run_g = 0u, run_e = 0u;
     for (int c0 = 0; c0 < n; c0 += 1024) {
       const int i = c0 + t;
@@ -1632,6 +1682,7 @@ __global__ void __launch_bounds__(1024) k_topk_small(const float* __restrict__ s
       run_g += tg;
       run_e += te;
       if (run_e >= remain && run_g >= n_greater) break;      // (uniform: everything wanted has been seen)
+    }
     }
   }
   __syncthreads();

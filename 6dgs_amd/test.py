@@ -252,7 +252,7 @@ class PoseStream:
     def __init__(self, id_module, rays_ori, rays_dirs, rays_rgb, k: int = 100, workspace=None, images_in_flight=None):
         self.idm, self.rays, self.k = id_module, (rays_ori, rays_dirs, rays_rgb), k
         self.workspace, self.images_in_flight = workspace, images_in_flight
-        self.image_stream = torch.cuda.Stream(device=rays_ori.device)
+        self.image_stream = torch.cuda.Stream(device=rays_ori.device)      # (a high-priority image stream was measured in round 6: no difference, profiles/r06_pipeline_ab.md)
         self._fence = None            # recorded on the caller's stream at the START of the previous submit
 
     @torch.no_grad()
