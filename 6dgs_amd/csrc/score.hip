@@ -217,6 +217,7 @@ constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
 constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
 constexpr int kSweepMaxImages = 8;      // 256-token SLOTS per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  SIXDGS_SWEEP_MAX_IMAGES=n overrides (the name is
                                         // round 4's, when a slot held one image); n <= 0 means "as many as the slot table holds": launches of 21, a last one of up to 31 (sweep_plan.h) -- NOT one launch for any batch
+constexpr int kPrepassReserveCus = 64;   // CUs the sample pre-pass leaves to other streams (-1: one-shot grid on all of them); see sixdgs_select_sample_stats
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
 // references [token group 8][ray half of the quad 2][token 32] fp32 = 2 KiB (the maximum of the 64 logits a lane produced
@@ -2192,7 +2193,22 @@ int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int
                          (float*)nullptr, w.slot_rows);
       LogitsF16Args V = select_args(w.slot_rows, T.n_slots, w, sample_planes, d_sample_scale, r_sample);
       V.q_quarter_scales = 1;
-      hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+      // (round 6) PERSISTENT on fewer workgroups than compute units: as a one-shot grid the pre-pass holds every CU for its ~1 ms, and the image side of
+      // the NEXT batch -- ~90 small dependent launches on another stream, which must finish inside the same window between two sweeps -- stands still.
+      // With `reserve` CUs left out (kPrepassReserveCus; SIXDGS_PREPASS_RESERVE_CUS overrides, -1 = the one-shot grid) the same groups are walked by
+      // (CUs - reserve) / slots sets: same partial statistics per group, hence the same bits.  Measured (profiles/r06_pipeline_ab.md): headline step - sweep
+      // 2.84 -> 2.61 ms with 64 of 256 left out (16: no gain, 128: less), cfg-2 11.58 -> 11.39 ms between poses, cfg-3 unchanged, one batch at a time +0.09 ms.
+      static const int reserve = [] { const char* e = getenv("SIXDGS_PREPASS_RESERVE_CUS"); return e ? atoi(e) : kPrepassReserveCus; }();
+      const int cus = sibling_sync_cus();
+      if (reserve >= 0 && cus > reserve && (cus - reserve) / T.n_slots >= 1) {
+        V.n_sets = (cus - reserve) / T.n_slots < V.n_groups ? (cus - reserve) / T.n_slots : V.n_groups;
+        V.sib_sync = nullptr;
+        V.sib_extra = 0u;
+        V.sib_period = kSibPeriod;
+        hipLaunchKernelGGL((k_logits_f16x<0, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
+      } else {
+        hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+      }
     }
     hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, s, w.partial, n_groups, T, row_stats, (float*)nullptr);
   }
