@@ -9,7 +9,8 @@ re-launches itself under torch.distributed.run on 127.0.0.1 with a free port (on
 
 Workload (config.workload).  `--config headline` (default) is the configuration BASELINE.json's metric is quoted on:
 synthetic 500 k-Gaussian scene (SURVEY.md §8(d) generator, seed 0), rays emitted from EVERY valid Gaussian with the
-iso-cell emitter at 64 rays per ellipsoid (R = 32.0 M rays), 800x800 uint8 query images, 4 images per GPU per step.
+iso-cell emitter at 64 rays per ellipsoid (R = 32.0 M rays), 800x800 uint8 query images, 8 images per GPU per step (rounds 1-5: 4;
+BASELINE.md's batches of 64 / 128 views over 8 GPUs are 8 / 16 per GPU; the 4-image figure stays in the line as `headline_b4`).
 The other presets are BASELINE.json's `configs` entries (sizes per SURVEY.md §8), each image-sharded over the ranks:
   cfg1  10 k Gaussians x 64 rays, one 400x400 query                     (configs[0]; the reference's CPU-runnable case)
   cfg2  300 k Gaussians read back from a 3DGS PLY, x 64 rays, one query  (configs[1])
@@ -54,7 +55,7 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X dense bf16/fp16 MFMA peak (same table)
 
 PRESETS = {
     #            Gaussians  rays/ellipsoid  images/GPU/step  query size  scene source        scorer
-    "headline": dict(gaussians=500_000, rays_per_ellipsoid=64, batch=4, image_size=800, scene="synthetic", scoring="resident"),
+    "headline": dict(gaussians=500_000, rays_per_ellipsoid=64, batch=8, image_size=800, scene="synthetic", scoring="resident"),
     "cfg1": dict(gaussians=10_000, rays_per_ellipsoid=64, batch=1, image_size=400, scene="synthetic", scoring="resident"),
     "cfg2": dict(gaussians=300_000, rays_per_ellipsoid=64, batch=1, image_size=800, scene="ply", scoring="resident"),
     "cfg3": dict(gaussians=1_000_000, rays_per_ellipsoid=64, batch=8, image_size=800, scene="synthetic", scoring="resident"),
@@ -106,7 +107,7 @@ def parse():
     ap.add_argument("--skip-reference-mode", action="store_true", help="skip the secondary reference-mode figure (1000-ellipsoid quadricell emission)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
-    ap.add_argument("--b8-steps", type=int, default=-1, help="headline: timed steps of the secondary 8-images-per-step figure (headline_b8); -1 = half of --steps, 0 = skip")
+    ap.add_argument("--b8-steps", type=int, default=-1, help="headline: timed steps of the secondary figure at the other images-per-step setting (headline_b4; headline_b8 under --batch 4); -1 = as many poses as half of --steps, 0 = skip")
     ap.add_argument("--scenes", default="", help="cfg5-standin: comma-separated substrings of the scene names to run (default: all twelve)")
     ap.add_argument("--scale", type=float, default=1.0, help="cfg5-standin: multiply every scene's Gaussian count (tests run the sweep at 1/100)")
     ap.add_argument("--views-cap", type=int, default=0, help="cfg5-standin: at most this many test views per scene (0 = the reference's counts)")
@@ -496,25 +497,29 @@ def main():
         out["config"]["tokens_per_image"] = [int(tk[i].shape[0]) for i in range(len(tk))]
     if cand is not None:
         out["config"]["select_candidates_last_batch"] = cand
-    # ---- secondary figure: the same scene at 8 images per GPU and step -- BASELINE.md's batches are 64 / 128 views over 8 GPUs = 8 / 16 per
-    # GPU; a sweep launch of 8 tiles shares every key tile 8 ways instead of 4 and the per-batch tail is paid once per 8 poses.  Same path, same pipeline.
-    if args.config == "headline" and pipelined and args.batch != 8 and args.b8_steps != 0 and args.mode == "full":
-        cams8 = syn.make_cameras(8, 500 + rank, width=args.image_size, height=args.image_size)
-        images8 = [torch.from_numpy(c["image"]).to(dev) for c in cams8]
-        gts8 = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in cams8]).to(dev)
-        tp.prime_image_graph(idm, images8)
-        ps8 = tp.PoseStream(idm, ori, dr, rgb)
+    # ---- secondary figure: the same scene at the OTHER images-per-step setting.  BASELINE.md's batches are 64 / 128 views over 8 GPUs = 8 / 16 per
+    # GPU: since round 6 the headline runs 8 images per GPU and step (a sweep launch of 8 tiles shares every key tile 8 ways instead of 4 and the per-batch
+    # tail is paid once per 8 poses; 16 = two such launches, measured equal: profiles/r06_images_per_step.md) and `headline_b4` is the 4-image figure
+    # of rounds 1-5 for continuity (with --batch 4 the roles swap: `headline_b8`).  Same path, same pipeline.
+    alt = 4 if args.batch == 8 else 8
+    if args.config == "headline" and pipelined and args.b8_steps != 0 and args.mode == "full":
+        camsa = syn.make_cameras(alt, 500 + rank, width=args.image_size, height=args.image_size)
+        imagesa = [torch.from_numpy(c["image"]).to(dev) for c in camsa]
+        gtsa = torch.stack([tp.gt_pose_and_intrinsics(pkg.CameraInfo(**c), dev)[0] for c in camsa]).to(dev)
+        tp.prime_image_graph(idm, imagesa)
+        psa = tp.PoseStream(idm, ori, dr, rgb)
         for _ in range(2):
-            ps8.collect(ps8.submit(images8, gts8))
-        n8 = max(2, args.steps // 2) if args.b8_steps < 0 else args.b8_steps
-        p8 = ops.KernelProfile()
-        e8, per8, _ = timed(n8, p8, ps=ps8, images=images8, gts=gts8, batch=8)
-        m8, f8, _, c8 = p8.collect()
-        out["headline_b8"] = {"value": round(world * 8 * n8 / e8, 4), "unit": "poses/s", "images_per_gpu_per_step": 8, "steps": n8, "ms_per_step": round(1e3 * e8 / n8, 3),
-                              "median_step_ms": round(1e3 * statistics.median(per8), 3), "sweep_avg_launch_ms": round(m8 / max(c8, 1), 4),
-                              "sweep_tflops": round(f8 / (m8 * 1e-3) / 1e12, 2) if m8 > 0 else None,
-                              "note": "the headline workload at 8 images per GPU and step (one sweep launch of 8 tiles), same pipeline; `value` above stays the 4-image figure of rounds 1-5"}
-        del ps8, images8, gts8
+            psa.collect(psa.submit(imagesa, gtsa))
+        na = max(2, (args.steps * args.batch) // (2 * alt)) if args.b8_steps < 0 else args.b8_steps
+        pa = ops.KernelProfile()
+        ea, pera, _ = timed(na, pa, ps=psa, images=imagesa, gts=gtsa, batch=alt)
+        ma, fa, _, ca = pa.collect()
+        out["headline_b%d" % alt] = {"value": round(world * alt * na / ea, 4), "unit": "poses/s", "images_per_gpu_per_step": alt, "steps": na, "ms_per_step": round(1e3 * ea / na, 3),
+                                     "median_step_ms": round(1e3 * statistics.median(pera), 3), "sweep_avg_launch_ms": round(ma / max(ca, 1), 4),
+                                     "sweep_tflops": round(fa / (ma * 1e-3) / 1e12, 2) if ma > 0 else None,
+                                     "note": ("the headline workload at %d images per GPU and step (one sweep launch of %d tiles), same pipeline" % (alt, alt))
+                                             + ("; this is what `value` was in rounds 1-5" if alt == 4 else "")}
+        del psa, imagesa, gtsa
         idm._select_ws = None
     if l24 is not None:
         out["two_pass_mode"] = l24
@@ -525,7 +530,10 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == inflight and tj.get("path", "two-pass") == ("select" if ("select" in path and not path.startswith("streamed")) else "two-pass"):
+                is_sel = "select" in path and not path.startswith("streamed")
+                sl = getattr(idm, "last_select_launches", None)
+                per_launch = (sl[0][1] if (is_sel and sl) else inflight)      # images the dominant kernel's launch scores: the select sweep's plan, or the two-pass workspace's share
+                if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == per_launch and tj.get("path", "two-pass") == ("select" if is_sel else "two-pass"):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = ("NOT measured in this run: copied from the builder's separate rocprofv3 --pmc pass over this same command (round %s): %s"
                                       % (tj.get("round"), tj.get("source", os.path.relpath(args.traffic_json, ROOT))))

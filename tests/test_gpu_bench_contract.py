@@ -43,7 +43,8 @@ def test_bench_single_gpu_json_contract():
     assert REQUIRED <= set(d) and "cpu_baseline" in d
     assert d["metric"] == "poses/sec" and d["unit"] == "poses/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    assert d["value"] > 0 and abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]      # 8 images per GPU and step since round 6
+    assert d["config"]["images_per_gpu_per_step"] == 8
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches"] >= 2 and r["avg_launch_ms"] > 0
@@ -72,7 +73,7 @@ def test_bench_two_ranks_code_path():
               "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2", "--gaussians", "8000", "--steps", "2", "--warmup", "1"],
              env={"SIXDGS_BENCH_BACKEND": "gloo", "SIXDGS_BENCH_FORCE_DEVICE": "0"})
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d       # baseline only on rank 0 at N = 1
-    assert abs(d["value"] - 2 * 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]   # whole-job aggregate over both ranks
+    assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]   # whole-job aggregate over both ranks
     assert d["ranks_seen"] == 2 and d["backend"] == "gloo"
 
 
@@ -105,9 +106,10 @@ def test_bench_pipelined_steps_give_the_poses_of_one_batch_at_a_time():
     b = _run([sys.executable, "-W", "ignore", *args, "--no-pipeline"], env={"SIXDGS_BENCH_DUMP_POSES": "1"})
     assert a["config"]["pipeline"].startswith("2 batches in flight") and b["config"]["pipeline"].startswith("none")
     assert a["config"]["scoring_path"] == b["config"]["scoring_path"] == "select"
-    assert a["poses_last_step"] == b["poses_last_step"] and len(a["poses_last_step"]) == 4
+    assert a["poses_last_step"] == b["poses_last_step"] and len(a["poses_last_step"]) == 8
     assert a["median_step"]["n"] == b["median_step"]["n"] == 4 and "completions" in a["median_step"]["note"]
-    assert a["config"]["select_sweep_launches"] == [[4, 4]]                 # four 256-token views: four tiles, one launch
+    assert a["headline_b4"]["images_per_gpu_per_step"] == 4 and a["headline_b4"]["value"] > 0 and "headline_b8" not in a      # the 4-image figure of rounds 1-5 beside it
+    assert a["config"]["select_sweep_launches"] == [[8, 8]]                 # eight 256-token views: eight tiles, one launch
 
 
 @pytest.mark.timeout(900)

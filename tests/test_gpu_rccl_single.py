@@ -44,7 +44,7 @@ def test_bench_over_rccl_with_one_rank_gives_the_poses_of_the_plain_run():
     assert a["backend"] == "none" and a["ranks_seen"] == 1
     assert b["backend"] == "nccl" and b["ranks_seen"] == 1 and b["n_gpus"] == 1       # ranks_seen: an all-reduce of ones on device memory over RCCL
     pa, pb = np.asarray(a["poses_last_step"]), np.asarray(b["poses_last_step"])
-    assert pa.shape == pb.shape == (4, 4, 4)
+    assert pa.shape == pb.shape == (8, 4, 4)
     assert np.array_equal(pa, pb)                                                     # scene + weights went through RCCL broadcasts, poses through the gather
 
 
