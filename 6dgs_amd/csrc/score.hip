@@ -287,6 +287,14 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       rowK[i] = row;
     }
     const char* qbase = A.qp + (int64_t)b * kT * kRowF;
+    // Cache policy of the key stream's loads (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1): `nt`.  A key tile is read once per launch by the workgroups of ONE
+    // sibling set, which meet after every tile -- all its readers pass within a tile's time -- while the q planes of the launch's slots are re-read for every
+    // tile by every set of the XCD.  With 8 slots those q planes are 3.1 MB of the XCD's 4 MB L2, and key lines without the hint displaced them: L2 <-> fabric
+    // traffic 1.44 x the algorithmic bytes at 8 tiles per launch; with it 1.02 x, the sweep the same or 0.2 % faster (profiles/r06_key_stream_nt.md; rounds
+    // 2-4 measured the hint at 2-4 slots per launch, where the q planes fit anyway: no difference, as again now).  -DSDG_KEY_AUX=0: the loads of rounds 1-5.
+#ifndef SDG_KEY_AUX
+#define SDG_KEY_AUX 2
+#endif
     auto issue_q = [&](const int s, const int qstage, const int i) {
       if (ABL & 1) return;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(qbase + (offQ[i] + (unsigned)(s * kSlabF))),
@@ -296,7 +304,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
       if (ABL & 8) return;
       const unsigned ob = (unsigned)min(rowK[i], lim) * kRowF + offK[i] + (unsigned)(s * kSlabF);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbase + ob),
-                                       (lds_ptr_t)(lds + kKBaseX + kstage * (2 * kQStageX) + (wave * 4 + i) * 1024), 16, 0, 0);
+                                       (lds_ptr_t)(lds + kKBaseX + kstage * (2 * kQStageX) + (wave * 4 + i) * 1024), 16, 0, SDG_KEY_AUX);
     };
     auto tile_lim = [&](int tile) {
       const int64_t left = A.r - (int64_t)tile * kBNX - 1;
