@@ -51,6 +51,36 @@ __device__ __forceinline__ int p_shift(float m) {
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 
+// Activation-plane loads and stores of the chain are NON-TEMPORAL (round 6): activations stream through the L2 once per pass (the sibling pass reads the same
+// lines at the same time) while the layer's weight planes are re-read from it for every tile.  Alternating processes on one box, 8 M rays (profiles/
+// r06_chain_nt_ab.log): 365.3 -> 369.9 TFLOP/s with both hints (loads alone 368.9, stores alone 365.1 -- round 2's "non-temporal output stores: no change"
+// stands on its own); L2 <-> fabric bytes unchanged (FETCH_SIZE +2 %, WRITE_SIZE the same): what improves is the weight planes' stay in L2, not the traffic.
+// Same keys bit for bit (cache hints).  -DSDG_ACT_NT=0 -DSDG_OUT_NT=0: the accesses of rounds 2-5.
+#ifndef SDG_ACT_NT
+#define SDG_ACT_NT 1
+#endif
+typedef unsigned dense_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_act(const char* p) {
+#if SDG_ACT_NT
+  const dense_u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const dense_u32x4_t*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
+#ifndef SDG_OUT_NT
+#define SDG_OUT_NT 1
+#endif
+typedef float dense_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_act(char* p, float a, float b, float c, float d) {
+#if SDG_OUT_NT
+  __builtin_nontemporal_store(dense_f32x4_t{a, b, c, d}, reinterpret_cast<dense_f32x4_t*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = float4{a, b, c, d};
+#endif
+}
+
 struct DenseArgs {
   const char* wp;        // weight planes [N][KS][128 B]
   const float* wmax;     // [N] max |w| per row (the weight row's scale is f3_scale(wmax[n]))
@@ -186,10 +216,10 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
   if ((J) < kWL) {                                                                                                        \
     P = *reinterpret_cast<const uint4*>(wbase + (min(wrow0 + 64u * (J) + lrow, wrmax) * wstride + lc16));                 \
   } else if (!INCM) {                                                                                                     \
-    P = *reinterpret_cast<const uint4*>(abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));                 \
+    P = ld_act(abase + (min(64u * ((J) - kWL) + lrow, lrmax) * astride + lc16));                                          \
   } else {                                                                                                                \
     const unsigned rl_ = min(64u * ((J) - kWL) + cm_lane, lrmax);                                                         \
-    P = *reinterpret_cast<const uint4*>(abase + dl::cm_src_offset(rl_, cm_chunk, astride));                               \
+    P = ld_act(abase + dl::cm_src_offset(rl_, cm_chunk, astride));                                                        \
   }
 #define SDG_LOAD_ALL() SDG_LOAD(0, p0) SDG_LOAD(1, p1) SDG_LOAD(2, p2) SDG_LOAD(3, p3) SDG_LOAD(4, p4) SDG_LOAD(5, p5) SDG_LOAD(6, p6) SDG_LOAD(7, p7)
 // LDS image of a slab (both layouts): row r (weights 0 .. FP-1, rays FP ..) at r * kPRow: [plane h 64 B | plane l 64 B].  DST = the stage's
@@ -469,8 +499,8 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
               char* const ob = A.out_planes + dl::cm_offset(gr, nslab_out, (f0 >> 5) + tm * 4 + wm_e, 0, lane_e >> 5);      // chunk 2 pp + h: + 2 pp runs
 #pragma unroll
               for (int pp = 0; pp < 2; ++pp) {
-                *reinterpret_cast<float4*>(ob + (2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp], acc[tm][tn][8 * pp + 1], acc[tm][tn][8 * pp + 4], acc[tm][tn][8 * pp + 5]};
-                *reinterpret_cast<float4*>(ob + (4 + 2 * pp) * kChunkRun) = float4{acc[tm][tn][8 * pp + 2], acc[tm][tn][8 * pp + 3], acc[tm][tn][8 * pp + 6], acc[tm][tn][8 * pp + 7]};
+                st_act(ob + (2 * pp) * kChunkRun, acc[tm][tn][8 * pp], acc[tm][tn][8 * pp + 1], acc[tm][tn][8 * pp + 4], acc[tm][tn][8 * pp + 5]);
+                st_act(ob + (4 + 2 * pp) * kChunkRun, acc[tm][tn][8 * pp + 2], acc[tm][tn][8 * pp + 3], acc[tm][tn][8 * pp + 6], acc[tm][tn][8 * pp + 7]);
               }
             }
           }
