@@ -157,6 +157,9 @@ struct LogitsF16Args {
 constexpr int kOutF32 = 0;     // logits as fp32 (blocked layout) + running (max, sumexp)
 constexpr int kOutL24 = 1;     // logits as 24-bit fixed point + running (max, sumexp)
 constexpr int kOutStats = 2;   // running (max, sumexp) only (the sample pre-pass of the select path)
+constexpr int kAblOneTerm = 8192;   // ABL bit (a product mode, not an ablation): only the h*h term of the three -- logits to ~2^-11 of |q||k| / sqrt(384).  For the sample
+                                    // pre-pass alone: its (max, sumexp) set the exponent offsets ref_t and the scale Z~_t of the sweep, whose g_t = Z_t / (f Z~_t) is EXACT
+                                    // relative to whatever Z~_t it was given -- the pre-pass decides how wide the bounds are, never the answer (include/sixdgs.h)
 constexpr int kOutUB = 3;      // per ray: sum_t exp(l_tr - ref_t) / (f Z~_t) (4 token-quarter partials); per token: the exact sum over rays
 
 // A wave-uniform global load through the scalar cache.  As a plain load hipcc emits global_load_dword (the kernel also
@@ -217,6 +220,7 @@ constexpr int kSibSpinLimit = 1 << 14;          // polls of ~0.3-1 us each
 constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival counter: every later target compares as reached
 constexpr int kSweepMaxImages = 8;      // 256-token SLOTS per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  SIXDGS_SWEEP_MAX_IMAGES=n overrides (the name is
                                         // round 4's, when a slot held one image); n <= 0 means "as many as the slot table holds": launches of 21, a last one of up to 31 (sweep_plan.h) -- NOT one launch for any batch
+constexpr bool kPrepassOneTermDefault = true;    // profiles/r06_prepass_one_term.md
 constexpr int kPrepassReserveCus = 64;   // CUs the sample pre-pass leaves to other streams (-1: one-shot grid on all of them); see sixdgs_select_sample_stats
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
@@ -232,6 +236,7 @@ constexpr int kLdsX = kKBaseX + 6 * kQStageX;   // 160 KiB
 template <int ABL, int OUT, bool PERS = false>
 __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
   constexpr bool L24 = OUT == kOutL24;
+  constexpr bool kOneTerm = (ABL & kAblOneTerm) != 0;
   __shared__ __attribute__((aligned(1024))) char lds[kLdsX];
   const unsigned w = xcd_remap(blockIdx.x, gridDim.x);
   const int bl = (int)(w % (unsigned)A.nb);
@@ -367,6 +372,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
+        if (kOneTerm && pl == 1) continue;      // (a fragment read whose result is never used must not be issued: its register is free for reuse before the data lands)
         a0[t][pl] = read_a(t, 0, pl, 0);
         b0[t][pl] = read_b(t, 0, pl, 0);
       }
@@ -434,7 +440,7 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
 #pragma unroll
           for (int z = 0; z < 4; ++z) {
             const int tm = z >> 1, tn = z & 1;
-            if (!(ABL & 4))
+            if (!(ABL & 4) && !((ABL & kAblOneTerm) && q < 2))
               acc[tm][2 * h + tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xb[tn][PB[q]], xa[tm][PA[q]], acc[tm][2 * h + tn], 0, 0, 0);
             side(q * 4 + z);
             __builtin_amdgcn_sched_barrier(0);
@@ -449,17 +455,20 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
         if (ABL & 2048) tstamp(0);
         // step 0: (k-step 0, ray half 0); read B(k-step 0, half 1)
         mfma_step(a0, b0, 0, [&](const int slot) {
+          if (kOneTerm && (slot & 1)) return;
           if (!(ABL & 16) && slot < 4) b1[slot >> 1][slot & 1] = read_b(2 + (slot >> 1), 0, slot & 1, ks3);
         });
         wait_lds();
         // step 1: (k-step 0, half 1); read A(k-step 1), B(k-step 1, half 0)
         mfma_step(a0, b1, 1, [&](const int slot) {
+          if (kOneTerm && (slot & 1)) return;
           if (!(ABL & 16) && slot < 4) a1[slot >> 1][slot & 1] = read_a(slot >> 1, 1, slot & 1, qs);
           else if (!(ABL & 16) && slot < 8) b0[(slot - 4) >> 1][slot & 1] = read_b((slot - 4) >> 1, 1, slot & 1, ks3);
         });
         wait_lds();
         // step 2: (k-step 1, half 0); read B(k-step 1, half 1) -- the last reads of this slab
         mfma_step(a1, b0, 0, [&](const int slot) {
+          if (kOneTerm && (slot & 1)) return;
           if (!(ABL & 16) && slot < 4) b1[slot >> 1][slot & 1] = read_b(2 + (slot >> 1), 1, slot & 1, ks3);
         });
         wait_lds();
@@ -472,8 +481,10 @@ __global__ void __launch_bounds__(512, 1) k_logits_f16x(LogitsF16Args A) {
         if (ABL & 2048) tstamp(3);
         // step 3: (k-step 1, half 1); read A / B(half 0) of slab sl+1; issue q(sl+2) -> q stage qs, key(sl+3) -> key stage ks3
         mfma_step(a1, b1, 1, [&](const int slot) {
-          if (!(ABL & 16) && slot < 4) a0[slot >> 1][slot & 1] = read_a(slot >> 1, 0, slot & 1, qn);
-          else if (!(ABL & 16) && slot < 8) b0[(slot - 4) >> 1][slot & 1] = read_b((slot - 4) >> 1, 0, slot & 1, kn);
+          if (!(kOneTerm && (slot & 1))) {
+            if (!(ABL & 16) && slot < 4) a0[slot >> 1][slot & 1] = read_a(slot >> 1, 0, slot & 1, qn);
+            else if (!(ABL & 16) && slot < 8) b0[(slot - 4) >> 1][slot & 1] = read_b((slot - 4) >> 1, 0, slot & 1, kn);
+          }
           if (slot < 4) issue_q((sl + 2) % 12, qs, slot);
           else if (slot < 8) {
             if (sl + 3 < 12) issue_k(kcur, lim_cur, sl + 3, ks3, slot - 4);
@@ -2175,6 +2186,12 @@ static int sweep_slot_cap() {
   return cap;
 }
 
+// The sample pre-pass with ONE of the three MFMA terms (kAblOneTerm).  SIXDGS_PREPASS_TERMS=3: all three (rounds 2-5).
+static bool prepass_one_term() {
+  static const bool one = [] { const char* e = getenv("SIXDGS_PREPASS_TERMS"); return e ? atoi(e) == 1 : kPrepassOneTermDefault; }();
+  return one;
+}
+
 int sixdgs_select_sweep_plan(const int32_t* h_n_tok, int batch, int32_t* slots_per_launch, int32_t* images_per_launch, int max_launches) {
   if (batch < 0 || batch > 32767 || max_launches < 0 || (max_launches > 0 && (!slots_per_launch || !images_per_launch))) return SIXDGS_E_BADARG;
   const std::vector<SweepSlots> plan = sweep_pack(h_n_tok, batch, sweep_slot_cap());
@@ -2213,9 +2230,11 @@ int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int
         V.sib_sync = nullptr;
         V.sib_extra = 0u;
         V.sib_period = kSibPeriod;
-        hipLaunchKernelGGL((k_logits_f16x<0, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
+        if (prepass_one_term()) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
+        else hipLaunchKernelGGL((k_logits_f16x<0, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
       } else {
-        hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+        if (prepass_one_term()) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+        else hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
       }
     }
     hipLaunchKernelGGL(k_merge_stats_slots, dim3((unsigned)T.n_images, 4), dim3(1024), 0, s, w.partial, n_groups, T, row_stats, (float*)nullptr);
