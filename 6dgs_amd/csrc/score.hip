@@ -2186,10 +2186,13 @@ static int sweep_slot_cap() {
   return cap;
 }
 
-// The sample pre-pass with ONE of the three MFMA terms (kAblOneTerm).  SIXDGS_PREPASS_TERMS=3: all three (rounds 2-5).
-static bool prepass_one_term() {
-  static const bool one = [] { const char* e = getenv("SIXDGS_PREPASS_TERMS"); return e ? atoi(e) == 1 : kPrepassOneTermDefault; }();
-  return one;
+// The sample pre-pass with ONE of the three MFMA terms (kAblOneTerm): launches of two or more slots.  With one slot (a single query: cfg-2) the pre-pass is
+// not matrix-bound (0.47 -> 0.36 ms) and the 64 CUs it leaves free are where the NEXT query's image side runs meanwhile: shortening it moved that image
+// side's end under the sweep, +0.1 ms between poses in four alternating runs (profiles/r06_prepass_one_term.md) -- so there all three terms stay.
+// SIXDGS_PREPASS_TERMS=3 / 1: three / one whatever the slot count.
+static bool prepass_one_term(int n_slots) {
+  static const int forced = [] { const char* e = getenv("SIXDGS_PREPASS_TERMS"); return e ? atoi(e) : 0; }();
+  return forced == 1 || (forced != 3 && kPrepassOneTermDefault && n_slots >= 2);
 }
 
 int sixdgs_select_sweep_plan(const int32_t* h_n_tok, int batch, int32_t* slots_per_launch, int32_t* images_per_launch, int max_launches) {
@@ -2230,10 +2233,10 @@ int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int
         V.sib_sync = nullptr;
         V.sib_extra = 0u;
         V.sib_period = kSibPeriod;
-        if (prepass_one_term()) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
+        if (prepass_one_term(T.n_slots)) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
         else hipLaunchKernelGGL((k_logits_f16x<0, kOutStats, true>), dim3((unsigned)(V.n_sets * T.n_slots)), dim3(512), 0, s, V);
       } else {
-        if (prepass_one_term()) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
+        if (prepass_one_term(T.n_slots)) hipLaunchKernelGGL((k_logits_f16x<kAblOneTerm, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
         else hipLaunchKernelGGL((k_logits_f16x<0, kOutStats>), dim3((unsigned)(V.n_groups * T.n_slots)), dim3(512), 0, s, V);
       }
     }

@@ -316,8 +316,8 @@ int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch
  * else: test.py:105-107).  Needs the scaled fp16 key planes of ALL r rays (sixdgs_ray_keys_ex, SIXDGS_MMA_F16X3) and those of a
  * ray SAMPLE (any r_sample <= r rays of the same scene, e.g. one ray in 16, through the same entry point).  score[r] =
  * sum_t e[t][r] / Z_t with e = exp(logit - ref_t), Z_t = sum_r e[t][r]:
- *   pre-pass    over the sample: ref_t = sample maximum, Z~_t = sample sum (so that f Z~_t ~ Z_t, f = r / r_sample).  Since round 6 with ONE of the
- *               three MFMA terms (h x h: logits to ~2^-11 |q||k| / sqrt(384); SIXDGS_PREPASS_TERMS=3 restores all three): these two only set the sweep's
+ *   pre-pass    over the sample: ref_t = sample maximum, Z~_t = sample sum (so that f Z~_t ~ Z_t, f = r / r_sample).  Since round 6, for launches of two or more 256-token slots, with ONE of the
+ *               three MFMA terms (h x h: logits to ~2^-11 |q||k| / sqrt(384); SIXDGS_PREPASS_TERMS=3 / 1 force three / one): these two only set the sweep's
  *               exponent offsets and scale -- g_t below is exact relative to WHATEVER Z~_t the sweep was given;
  *   main sweep  over all rays, one matrix-core pass, nothing of size T x R leaves the chip: U[r] = sum_t e[t][r] / (f Z~_t)
  *               (4 x 4 B per ray and image instead of 784 B of logits) and the EXACT g_t = Z_t / (f Z~_t);

@@ -487,6 +487,28 @@ def test_sweep_launch_grouping_is_invisible(ops, tmp_path):
         assert np.array_equal(idx.cpu().numpy()[0], a["idx"][i]) and int(st[0]) == int(a["status"][i])
 
 
+def test_prepass_terms_do_not_change_the_answer(ops, tmp_path):
+    """Round 6: the sample pre-pass issues one MFMA term of three (its statistics set the sweep's exponent offsets and scale only; g_t is exact relative to
+    them).  Against SIXDGS_PREPASS_TERMS=3: the same top-100 lists, values to 1e-6 (the exact re-score's, relative to slightly different offsets), about as many
+    candidates -- over ragged token counts incl. a 1-token and a 31-token image."""
+    import subprocess
+    child = _CHILD.replace("[256, 200, 256, 31]", "[256, 200, 256, 31, 1, 137, 64, 256]")
+    outs = {}
+    for terms in ("", "3"):
+        f = str(tmp_path / f"terms{terms or 'default'}.npz")
+        env = dict(os.environ, SIXDGS_TEST_ROOT=ROOT)
+        env.pop("SIXDGS_PREPASS_TERMS", None)
+        if terms:
+            env["SIXDGS_PREPASS_TERMS"] = terms
+        p = subprocess.run([sys.executable, "-W", "ignore", "-c", child, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[terms] = np.load(f)
+    a, b = outs[""], outs["3"]
+    assert a["idx"].shape == (8, 100) and np.array_equal(a["idx"], b["idx"])
+    assert np.allclose(np.nan_to_num(a["val"], nan=-7.0), np.nan_to_num(b["val"], nan=-7.0), rtol=1e-6, atol=0)
+    assert (np.sign(a["status"]) == np.sign(b["status"])).all() and (np.abs(a["status"] - b["status"]) <= np.maximum(8, b["status"] // 10)).all(), (a["status"], b["status"])
+
+
 def test_streamed_scene_with_an_arena_survives_a_refused_image(ops, syn):
     """with an arena installed a scene is streamed BECAUSE its planes exceed the arena -- the two-pass fallback of the streamed select path
     (a refused image) used to carve every chunk's planes from the arena in both sweeps without giving them back and died with "arena exhausted".  Here:
