@@ -22,7 +22,7 @@ sz = C.c_size_t
 
 
 PROFILE_SLOTS = 128
-ABI_VERSION = 6          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
+ABI_VERSION = 7          # must equal SIXDGS_ABI_VERSION in include/sixdgs.h (checked by __graft_entry__.post_build_checks)
 
 
 class Profile(C.Structure):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "sixdgs_tok_attention": (i32, [vp, i64, i32, i32, i32, vp, i64, vp]),
     "sixdgs_im2col": (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sixdgs_u8_to_planar": (i32, [vp, i32, i64, vp, vp, vp]),
+    "sixdgs_image_prep": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sixdgs_tok_pack_bytes": (sz, [i32, i32]),
     "sixdgs_tok_pack": (i32, [vp, i32, i32, i64, vp, vp, vp]),
     "sixdgs_tok_linear": (i32, [vp, i64, i32, i64, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, vp, i64, vp, vp, i64, vp]),

@@ -327,6 +327,15 @@ class BackboneWrapper(torch.nn.Module):
         """[n,H,W,3] fp32 (same size, no alpha) -> [n,3,224,224]"""
         return self.transformations(imgs.permute(0, 3, 1, 2))
 
+    def preprocess_batch_u8(self, imgs_u8, table256):
+        """[n,H,W,3] uint8 on the GPU (same size, no alpha) -> [n,3,224,224] through ONE kernel (ops.image_prep: table lookup, antialiased bicubic resize, crop,
+        normalisation -- the arithmetic of `transformations` on `table256[value]`), or None where it does not apply (the caller then converts and calls
+        preprocess_batch)."""
+        from . import ops
+        if not (ops.image_prep_enabled() and imgs_u8.is_cuda and imgs_u8.dtype == torch.uint8):
+            return None
+        return ops.image_prep(imgs_u8, table256, IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD, 256, 224)
+
     def position_encoding(self, dtype, device):
         key = (dtype, str(device))
         if key not in self._pe_cache:

@@ -221,6 +221,7 @@ constexpr unsigned kSibReleased = 0x40000000u;  // OR-ed into a set's arrival co
 constexpr int kSweepMaxImages = 8;      // 256-token SLOTS per sweep launch (the last launch of a batch: up to 12); see sixdgs_select_sweep.  SIXDGS_SWEEP_MAX_IMAGES=n overrides (the name is
                                         // round 4's, when a slot held one image); n <= 0 means "as many as the slot table holds": launches of 21, a last one of up to 31 (sweep_plan.h) -- NOT one launch for any batch
 constexpr bool kPrepassOneTermDefault = true;    // profiles/r06_prepass_one_term.md
+constexpr int kPrepassReserveCusOneSlot = 160;
 constexpr int kPrepassReserveCus = 64;   // CUs the sample pre-pass leaves to other streams (-1: one-shot grid on all of them); see sixdgs_select_sample_stats
 constexpr int kSibPeriod = 1;            // tiles between two meetings of a sibling set (mode 1).  Round 3 measured 4 and 8: 1.24x / 1.25x the algorithmic bytes against 1.05-1.14x
 // 24-bit logits: per 128-ray tile [token group 8][ray quad 32][token 32][4 x 24 bit = 12 B] = 96 KiB, followed by the
@@ -2186,13 +2187,12 @@ static int sweep_slot_cap() {
   return cap;
 }
 
-// The sample pre-pass with ONE of the three MFMA terms (kAblOneTerm): launches of two or more slots.  With one slot (a single query: cfg-2) the pre-pass is
-// not matrix-bound (0.47 -> 0.36 ms) and the 64 CUs it leaves free are where the NEXT query's image side runs meanwhile: shortening it moved that image
-// side's end under the sweep, +0.1 ms between poses in four alternating runs (profiles/r06_prepass_one_term.md) -- so there all three terms stay.
-// SIXDGS_PREPASS_TERMS=3 / 1: three / one whatever the slot count.
-static bool prepass_one_term(int n_slots) {
+// The sample pre-pass with ONE of the three MFMA terms (kAblOneTerm) -- for every launch, whatever its slot count: an image's statistics, candidates and
+// values must not depend on what it was batched with (test_token_packing_is_invisible..., test_sweep_launch_grouping_is_invisible).
+// SIXDGS_PREPASS_TERMS=3: all three (rounds 2-5).
+static bool prepass_one_term(int /*n_slots*/) {
   static const int forced = [] { const char* e = getenv("SIXDGS_PREPASS_TERMS"); return e ? atoi(e) : 0; }();
-  return forced == 1 || (forced != 3 && kPrepassOneTermDefault && n_slots >= 2);
+  return forced == 1 || (forced != 3 && kPrepassOneTermDefault);
 }
 
 int sixdgs_select_sweep_plan(const int32_t* h_n_tok, int batch, int32_t* slots_per_launch, int32_t* images_per_launch, int max_launches) {
@@ -2226,7 +2226,11 @@ int sixdgs_select_sample_stats(const float* q, const int32_t* d_n_tok, const int
       // With `reserve` CUs left out (kPrepassReserveCus; SIXDGS_PREPASS_RESERVE_CUS overrides, -1 = the one-shot grid) the same groups are walked by
       // (CUs - reserve) / slots sets: same partial statistics per group, hence the same bits.  Measured (profiles/r06_pipeline_ab.md): headline step - sweep
       // 2.84 -> 2.61 ms with 64 of 256 left out (16: no gain, 128: less), cfg-2 11.58 -> 11.39 ms between poses, cfg-3 unchanged, one batch at a time +0.09 ms.
-      static const int reserve = [] { const char* e = getenv("SIXDGS_PREPASS_RESERVE_CUS"); return e ? atoi(e) : kPrepassReserveCus; }();
+      static const int reserve_env = [] { const char* e = getenv("SIXDGS_PREPASS_RESERVE_CUS"); return e ? atoi(e) : -2; }();
+      // one slot (a single query per step: cfg-2): the pre-pass is short and not matrix-bound, and the window it opens is what the NEXT query's image side (1 ms of
+      // small dependent launches) lives on -- 160 CUs left out instead of 64 (profiles/r06_prepass_one_term.md: with the one-term pre-pass 11.24 / 11.25 / 11.20 /
+      // 11.16 ms between poses at 64 / 96 / 128 / 160, three terms at 64: 11.14).  The reserve never changes a bit: the same groups, walked by fewer sets.
+      const int reserve = reserve_env != -2 ? reserve_env : (T.n_slots == 1 ? kPrepassReserveCusOneSlot : kPrepassReserveCus);
       const int cus = sibling_sync_cus();
       if (reserve >= 0 && cus > reserve && (cus - reserve) / T.n_slots >= 1) {
         V.n_sets = (cus - reserve) / T.n_slots < V.n_groups ? (cus - reserve) / T.n_slots : V.n_groups;

@@ -583,6 +583,123 @@ __global__ void __launch_bounds__(256) k_u8_to_planar(const uint8_t* __restrict_
   }
 }
 
+// a16 + the transform pipeline of backbone.py:52-77 for a batch of RGB images in ONE pass (round 6): uint8 [B][H][W][3] -> table lookup (value / 255, the caller's
+// CPU-built table) -> antialiased bicubic resize to (nh, nw) -> centre crop S x S -> (x - mean) / std -> fp32 [B][3][S][S].  Replaces k_u8_to_planar + PyTorch's
+// upsample_gen2d_aa (every output pixel re-forms its ~15 x 15 window: 0.29 ms per 16 images of 800 x 800) + the crop / normalise kernels.
+// The arithmetic is that of the op it replaces -- PyTorch's antialias path (UpSampleBilinear2d.cu: _compute_weights_span, _compute_weights, the a = -0.5 cubic filter,
+// interpolate_aa_single_dim), in its order: per output index i of the RESIZED grid, centre = scale (i + 0.5), span [xmin, xmin + xsize) = (int)(centre -+ support + 0.5)
+// clipped to the input, weights filter((j + xmin - centre + 0.5) / scale) normalised by their sum in tap order; a window's rows are first reduced along x, then along y, each as
+// a tap-order sum that starts from the first product.  What differs is only WHO computes a row's x-reduction: here once per (input row, output column) of a band of
+// output rows, shared through LDS by the band's rows (separable), there once per output pixel.  The same products in the same order: equal up to the compiler's choice of
+// fused multiply-adds (tests: <= 2e-6 of the op's result on [-2.2, 2.7]-ranged values).
+// One workgroup = (band of rb output rows, image).  LDS: table | wx [S][kt] | x spans | wy [rb][kt] | y spans | x-reduced rows [nr][3][S].
+struct PrepArgs {
+  const uint8_t* in;
+  const float* lut;
+  float* out;
+  int H, W, top, left, S, rb, kt, nrmax;
+  float sh, sw, sup_h, sup_w;       // input / resized size per axis; support = 2 scale (scale >= 1), else 2
+  float mean[3], stdv[3];
+  int64_t last_dword;               // index of the last dword that holds image bytes (loads are clamped to it)
+};
+
+__device__ __forceinline__ float aa_cubic(float x) {      // upsample_antialias::BicubicFilterFunctor, a = -0.5
+  const float a = -0.5f;
+  x = fabsf(x);
+  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+  return 0.f;
+}
+
+// span and normalised weights of output index i (of the resized grid) along an axis of n input samples; w[0 .. kt): zero beyond xsize
+__device__ __forceinline__ void aa_weights(int i, int n, float scale, float support, int kt, float* w, int* meta) {
+  const float center = scale * ((float)i + 0.5f);
+  const int xmin = max((int)(center - support + 0.5f), 0);
+  const int xsize = min((int)(center + support + 0.5f), n) - xmin;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const float xmc = (float)xmin - center;
+  float total = 0.f;
+  for (int j = 0; j < kt; ++j) {
+    float v = 0.f;
+    if (j < xsize) {
+      v = aa_cubic(((float)j + xmc + 0.5f) * invscale);
+      total += v;
+    }
+    w[j] = v;
+  }
+  if (total != 0.f)
+    for (int j = 0; j < xsize && j < kt; ++j) w[j] /= total;
+  meta[0] = xmin;
+  meta[1] = xsize < kt ? xsize : kt;
+}
+
+__global__ void __launch_bounds__(256) k_image_prep(PrepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float prep_sm[];
+  float* const tab = prep_sm;
+  float* const wx = tab + 256;
+  int* const xmeta = reinterpret_cast<int*>(wx + A.S * A.kt);
+  float* const wy = reinterpret_cast<float*>(xmeta + 2 * A.S);
+  int* const ymeta = reinterpret_cast<int*>(wy + A.rb * A.kt);
+  float* const hbuf = reinterpret_cast<float*>(ymeta + 2 * A.rb);
+  const int tid = threadIdx.x, b = blockIdx.y, oy0 = blockIdx.x * A.rb;
+  const int rows = min(A.rb, A.S - oy0);
+  tab[tid] = A.lut[tid];
+  for (int x = tid; x < A.S; x += 256) aa_weights(A.left + x, A.W, A.sw, A.sup_w, A.kt, wx + x * A.kt, xmeta + 2 * x);
+  if (tid < rows) aa_weights(A.top + oy0 + tid, A.H, A.sh, A.sup_h, A.kt, wy + tid * A.kt, ymeta + 2 * tid);
+  __syncthreads();
+  const int r0 = ymeta[0];
+  int r1 = r0;
+  for (int ry = 0; ry < rows; ++ry) r1 = max(r1, ymeta[2 * ry] + ymeta[2 * ry + 1]);
+  const int nr = min(r1 - r0, A.nrmax);
+  // ---- along x: item = (input row r0 + r, output column x); its 3 * xsize bytes start anywhere: aligned dwords, shifted into place (v_alignbyte), 4 pixels = 3 dwords at a time
+  const uint32_t* const base = reinterpret_cast<const uint32_t*>(A.in);
+  const int groups = A.kt >> 2;
+  for (int it = tid; it < nr * A.S; it += 256) {
+    const int r = it / A.S, x = it - r * A.S;
+    const int xmin = xmeta[2 * x];
+    const int64_t byte0 = (((int64_t)b * A.H + (r0 + r)) * A.W + xmin) * 3;
+    const unsigned sh8 = (unsigned)(byte0 & 3);
+    const int64_t d0i = byte0 >> 2;
+    const float* w = wx + x * A.kt;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    uint32_t carry = base[min(d0i, A.last_dword)];
+    for (int g = 0; g < groups; ++g) {
+      const uint32_t n0 = base[min(d0i + 3 * g + 1, A.last_dword)], n1 = base[min(d0i + 3 * g + 2, A.last_dword)], n2 = base[min(d0i + 3 * g + 3, A.last_dword)];
+      const uint32_t e0 = __builtin_amdgcn_alignbyte(n0, carry, sh8), e1 = __builtin_amdgcn_alignbyte(n1, n0, sh8), e2 = __builtin_amdgcn_alignbyte(n2, n1, sh8);
+      carry = n2;
+      const float4 wv = *reinterpret_cast<const float4*>(w + 4 * g);
+      a0 = __builtin_fmaf(tab[e0 & 255u], wv.x, a0);
+      a1 = __builtin_fmaf(tab[(e0 >> 8) & 255u], wv.x, a1);
+      a2 = __builtin_fmaf(tab[(e0 >> 16) & 255u], wv.x, a2);
+      a0 = __builtin_fmaf(tab[e0 >> 24], wv.y, a0);
+      a1 = __builtin_fmaf(tab[e1 & 255u], wv.y, a1);
+      a2 = __builtin_fmaf(tab[(e1 >> 8) & 255u], wv.y, a2);
+      a0 = __builtin_fmaf(tab[(e1 >> 16) & 255u], wv.z, a0);
+      a1 = __builtin_fmaf(tab[e1 >> 24], wv.z, a1);
+      a2 = __builtin_fmaf(tab[e2 & 255u], wv.z, a2);
+      a0 = __builtin_fmaf(tab[(e2 >> 8) & 255u], wv.w, a0);
+      a1 = __builtin_fmaf(tab[(e2 >> 16) & 255u], wv.w, a1);
+      a2 = __builtin_fmaf(tab[e2 >> 24], wv.w, a2);
+    }
+    hbuf[(r * 3 + 0) * A.S + x] = a0;
+    hbuf[(r * 3 + 1) * A.S + x] = a1;
+    hbuf[(r * 3 + 2) * A.S + x] = a2;
+  }
+  __syncthreads();
+  // ---- along y, normalisation, planar store (consecutive threads = consecutive x: conflict-free LDS reads, coalesced stores)
+  for (int it = tid; it < rows * 3 * A.S; it += 256) {
+    const int x = it % A.S, c = (it / A.S) % 3, ry = it / (3 * A.S);
+    const int ymin = ymeta[2 * ry] - r0, ysize = ymeta[2 * ry + 1];
+    const float* w = wy + ry * A.kt;
+    float acc = 0.f;
+    for (int j = 0; j < ysize; ++j) {
+      const int rr = min(ymin + j, nr - 1);
+      acc = __builtin_fmaf(hbuf[(rr * 3 + c) * A.S + x], w[j], acc);
+    }
+    A.out[(((int64_t)b * 3 + c) * A.S + (oy0 + ry)) * A.S + x] = (acc - A.mean[c]) / A.stdv[c];
+  }
+}
+
 int tok_ft_per_wg(int64_t token_tiles, int n_ft, bool multi) {
   if (multi) return 1;                                     // every chunk re-stages the token tile: nothing to share between feature tiles
   static const int forced = [] { const char* e = getenv("SIXDGS_TOK_FTPW"); return e ? atoi(e) : 0; }();      // (developer hook: tools/time_vit_gemms.py)
@@ -683,6 +800,45 @@ int sixdgs_u8_to_planar(const uint8_t* images, int batch, int64_t pixels, const 
   const int64_t total4 = (int64_t)batch * (pixels / 4);
   const int64_t grid = sdg_cdiv(total4, 256);
   hipLaunchKernelGGL(k_u8_to_planar, dim3((unsigned)(grid < 8192 ? grid : 8192)), dim3(256), 0, sdg_stream(stream), images, table256, pixels, total4, out);
+  SDG_LAUNCH_OK();
+  return 0;
+}
+
+// images [batch][height][width][3] uint8 -> out [batch][3][out_size][out_size] fp32: see include/sixdgs.h
+int sixdgs_image_prep(const uint8_t* images, int batch, int height, int width, const float* table256, int resized_h, int resized_w, int crop_top, int crop_left,
+                      int out_size, const float* mean3, const float* std3, float* out, sixdgs_stream_t stream) {
+  SDG_CHECK_ARG(batch >= 0 && height > 0 && width > 0 && resized_h > 0 && resized_w > 0 && out_size > 0 && crop_top >= 0 && crop_left >= 0 &&
+                crop_top + out_size <= resized_h && crop_left + out_size <= resized_w && mean3 && std3);
+  if (batch == 0) return 0;
+  SDG_CHECK_ARG(images && table256 && out && ((uintptr_t)images % 4) == 0 && (int64_t)batch * height * width * 3 < (int64_t)1 << 40 && batch <= 65535);
+  PrepArgs A;
+  A.in = images; A.lut = table256; A.out = out;
+  A.H = height; A.W = width; A.top = crop_top; A.left = crop_left; A.S = out_size;
+  A.sh = (float)height / (float)resized_h;                 // area_pixel_compute_scale, align_corners = false, no scale factor given
+  A.sw = (float)width / (float)resized_w;
+  A.sup_h = A.sh >= 1.f ? 2.f * A.sh : 2.f;                // (interp_size 4) / 2 * scale
+  A.sup_w = A.sw >= 1.f ? 2.f * A.sw : 2.f;
+  const float sup = A.sup_h > A.sup_w ? A.sup_h : A.sup_w;
+  const int taps = (int)ceilf(sup) * 2 + 1;                // the op's own window size
+  A.kt = (taps + 3) & ~3;
+  if (A.kt > 64) return SIXDGS_E_UNSUPPORTED;              // (scale > 15: not a query image of this pipeline)
+  for (int c = 0; c < 3; ++c) { A.mean[c] = mean3[c]; A.stdv[c] = std3[c]; }
+  A.last_dword = ((int64_t)batch * height * width * 3 - 1) >> 2;
+  // band height: 8 output rows for batches that fill the chip anyway, 4 below (more workgroups, shorter each); fewer when the x-reduced rows do not fit 150 KB of LDS
+  size_t lds = 0;
+  for (A.rb = (int64_t)batch * sdg_cdiv(out_size, 8) >= 256 ? 8 : 4; A.rb >= 1; A.rb >>= 1) {
+    A.nrmax = (int)((float)A.rb * A.sh + 2.f * A.sup_h) + 3;
+    lds = sizeof(float) * (256 + (size_t)out_size * A.kt + 2 * (size_t)out_size + (size_t)A.rb * A.kt + 2 * (size_t)A.rb + (size_t)A.nrmax * 3 * out_size);
+    if (lds <= 150 * 1024) break;
+  }
+  if (A.rb < 1) return SIXDGS_E_UNSUPPORTED;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_prep), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    lds_set = 150 * 1024;
+  }
+  hipLaunchKernelGGL(k_image_prep, dim3((unsigned)sdg_cdiv(out_size, A.rb), (unsigned)batch), dim3(256), lds, sdg_stream(stream), A);
   SDG_LAUNCH_OK();
   return 0;
 }

@@ -213,6 +213,16 @@ class IdentificationModule(torch.nn.Module):
 
     # ---- image side (PyTorch-ROCm) --------------------------------------------------------------------
     @torch.no_grad()
+    def image_tokens_u8(self, imgs_u8: torch.Tensor, table256: torch.Tensor):
+        """A batch of RGB query images of one size as they arrive -- uint8 [B,H,W,3] on the GPU -- -> what image_tokens returns for them, with the whole
+        transform pipeline in one kernel (BackboneWrapper.preprocess_batch_u8); None when that kernel does not apply."""
+        bw = self.backbone_wrapper
+        norm = bw.preprocess_batch_u8(imgs_u8, table256)
+        if norm is None:
+            return None
+        return bw.assemble_batch(bw.features_from_norm(norm))
+
+    @torch.no_grad()
     def image_tokens(self, imgs: Sequence[torch.Tensor], masks: Sequence[Optional[torch.Tensor]]):
         """Batch of images (any sizes; mask None = no alpha channel) -> (tokens, fmaps [B,384,16,16]) where tokens is a
         list of [T_i,398] tensors, or ONE [B,256,398] tensor when every image keeps all 256 tokens and all share a size

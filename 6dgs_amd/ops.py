@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -412,6 +413,43 @@ def u8_to_planar(images_u8: torch.Tensor, table256: torch.Tensor) -> torch.Tenso
     b, h, w, _ = x.shape
     out = torch.empty(b, 3, h, w, device=x.device)
     check(_lib.load().sixdgs_u8_to_planar(_p(x), b, h * w, _p(t), _p(out), _stream()), "u8_to_planar")
+    return out
+
+
+def image_prep_geometry(h: int, w: int, resize: int = 256, crop: int = 224):
+    """The geometry of torchvision's Resize(resize) + CenterCrop(crop) on an h x w image, as BackboneWrapper applies them (backbone.py:52-77):
+    -> (resized_h, resized_w, crop_top, crop_left)."""
+    if h <= w:
+        nh, nw = resize, int(resize * w / h)
+    else:
+        nh, nw = int(resize * h / w), resize
+    return nh, nw, int(round((nh - crop) / 2.0)), int(round((nw - crop) / 2.0))
+
+
+def image_prep_enabled() -> bool:
+    """SIXDGS_IMAGE_PREP=0: uniform RGB batches go through sixdgs_u8_to_planar + PyTorch's antialiased resize, crop and normalisation as before round 6's last step."""
+    return os.environ.get("SIXDGS_IMAGE_PREP", "1") != "0"
+
+
+@_on_device
+def image_prep(images_u8: torch.Tensor, table256: torch.Tensor, mean, std, resize: int = 256, crop: int = 224) -> Optional[torch.Tensor]:
+    """[B, H, W, 3] uint8 -> [B, 3, crop, crop] fp32 = Normalize(CenterCrop(Resize_bicubic_antialias(table256[value]))) in one launch (sixdgs_image_prep);
+    None when the kernel does not take the shape (the caller then uses PyTorch's kernels).  mean / std: three floats each."""
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[-1] != 3:
+        raise RuntimeError(f"6dgs_amd: image_prep needs uint8 [B, H, W, 3], got {images_u8.dtype} {tuple(images_u8.shape)}")
+    x = images_u8.contiguous()
+    t = _f32(table256)
+    _need_gpu(x, t)
+    b, h, w, _ = x.shape
+    nh, nw, top, left = image_prep_geometry(h, w, resize, crop)
+    if (nh, nw) == (h, w) or nh < crop or nw < crop or t.numel() != 256:
+        return None
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    out = torch.empty(b, 3, crop, crop, device=x.device)
+    st = _lib.load().sixdgs_image_prep(_p(x), b, h, w, _p(t), nh, nw, top, left, crop, m3, s3, _p(out), _stream())
+    if st == -3:                  # SIXDGS_E_UNSUPPORTED: scale / window beyond the kernel's LDS
+        return None
+    check(st, "image_prep")
     return out
 
 

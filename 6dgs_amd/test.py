@@ -81,6 +81,21 @@ def prepare_images_device(images):
     return out_i, out_m
 
 
+def image_side_tokens(id_module, images):
+    """uint8 device images -> (tokens, feature maps): RGB images of one shape go from uint8 to normalised 224 x 224 planes in one kernel
+    (IdentificationModule.image_tokens_u8); everything else -- alpha channels, mixed sizes, shapes that kernel does not take -- through
+    prepare_images_device + image_tokens as before."""
+    n = len(images)
+    if n >= 1 and ops.image_prep_enabled() and all(im.shape == images[0].shape and im.dim() == 3 and im.shape[-1] == 3 and im.dtype == torch.uint8 and im.is_cuda
+                                                 for im in images):
+        stacked = images if isinstance(images, torch.Tensor) else (images[0][None] if n == 1 else torch.stack(list(images)))
+        res = id_module.image_tokens_u8(stacked, _u8_lut(stacked.device))
+        if res is not None:
+            return res
+    imgs_f, masks = prepare_images_device(images)
+    return id_module.image_tokens(imgs_f, masks)
+
+
 class _ImageSideGraph:
     """hipGraphs of the image side of a batch: (a) uint8 -> fp32, resize / crop / normalise, ViT-S/14, token assembly; (b) the camera-up CNN on
     (a)'s feature maps -- ~250 small launches that are launch-bound at 1..16 images.  One pair per (module weights, batch shape); inputs are
@@ -147,8 +162,7 @@ class _ImageSideGraph:
         return self.up
 
     def _vit(self, id_module):
-        imgs_f, masks = prepare_images_device(self.inp)
-        return id_module.image_tokens(imgs_f, masks)
+        return image_side_tokens(id_module, self.inp)
 
 
 @torch.no_grad()
@@ -180,8 +194,7 @@ def estimate_poses(id_module, images, rays_ori, rays_dirs, rays_rgb, gt_c2w=None
         if res is not None and not isinstance(res[0], (list, tuple)):
             tokens, up = res
         else:
-            imgs_f, masks = prepare_images_device(images)
-            tokens, fmaps = id_module.image_tokens(imgs_f, masks)
+            tokens, fmaps = image_side_tokens(id_module, images)
             up = id_module.camera_up(fmaps)
     if streamed_chunk_rays:       # no resident key cache: ray chunks through ray MLP + scorer (scenes beyond one GPU's HBM)
         idx, weights = id_module.score_tokens_streamed(tokens, rays_ori, rays_dirs, rays_rgb, k, chunk_rays=int(streamed_chunk_rays),
@@ -282,8 +295,7 @@ class PoseStream:
                     up_ready = torch.cuda.Event()
                     up_ready.record(side)
                 else:
-                    imgs_f, masks = prepare_images_device(images)
-                    tokens, fmaps = self.idm.image_tokens(imgs_f, masks)
+                    tokens, fmaps = image_side_tokens(self.idm, images)
                     up = self.idm.camera_up(fmaps)
                     ready = torch.cuda.Event()
                     ready.record(side)
@@ -342,8 +354,7 @@ def estimate_poses_ray_sharded(id_module, images, rays_ori, rays_dirs, rays_rgb,
         if res is not None and not isinstance(res[0], (list, tuple)):
             tokens, up = res
         else:
-            imgs_f, masks = prepare_images_device(images)
-            tokens, fmaps = id_module.image_tokens(imgs_f, masks)
+            tokens, fmaps = image_side_tokens(id_module, images)
             up = id_module.camera_up(fmaps)
     idx, weights = id_module.score_tokens_ray_sharded(tokens, rays_ori, rays_dirs, rays_rgb, ray_offset, r_total, k, group=group, profile=profile)
     sel_o, sel_d = dd.gather_selected_rays(idx, rays_ori, rays_dirs, ray_offset, group)
@@ -479,9 +490,15 @@ def test_pose_estimation(
             toks = [t.to(dev) for t in token_override[b0:b0 + nb]]
             up = up_override[b0:b0 + nb].to(dev)
         else:
-            prepared = [prepare_image(c.image, dev) for c in cams]
-            has_alpha = [np.asarray(c.image).shape[-1] == 4 for c in cams]
-            toks, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] if a else None for p, a in zip(prepared, has_alpha)])
+            arrs = [np.asarray(c.image) for c in cams]
+            has_alpha = [a.shape[-1] == 4 for a in arrs]
+            rgb_u8 = all(a.dtype == np.uint8 and a.ndim == 3 and a.shape == arrs[0].shape and a.shape[-1] == 3 for a in arrs)
+            will_save = bool(save) and (b0 == 0 or bool(save_all))
+            prepared = None if (rgb_u8 and not will_save) else [prepare_image(c.image, dev) for c in cams]
+            if rgb_u8:      # the same image side as the pipelined pass (one kernel from uint8 to normalised planes where it applies): same results bit for bit
+                toks, fmaps = image_side_tokens(id_module, [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs])
+            else:
+                toks, fmaps = id_module.image_tokens([p[0] for p in prepared], [p[1] if a else None for p, a in zip(prepared, has_alpha)])
             up = id_module.camera_up(fmaps)
         saving = [bool(save) and (b0 + i == 0 or bool(save_all)) for i in range(nb)]
         idx, weights, pred_scores = id_module.score_tokens(toks, rays_ori, rays_dirs, rays_rgb, k, want_scores=loss_fn is not None or any(saving))

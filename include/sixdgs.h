@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SIXDGS_ABI_VERSION 6   /* 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion), sixdgs_tok_attention, sixdgs_im2col, sixdgs_u8_to_planar; the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
+#define SIXDGS_ABI_VERSION 7   /* 7: sixdgs_image_prep (uint8 -> resized, cropped, normalised planar fp32 in one pass); 6: sixdgs_tok_pack / sixdgs_tok_linear (dense products of the backbone stage on packed weight planes, with LayerNorm / GELU / residual fusion), sixdgs_tok_attention, sixdgs_im2col, sixdgs_u8_to_planar; the three-plane bf16 key format and its scorer kernel removed (sixdgs_split_planes, sixdgs_key_planes_bytes gone; key planes exist as scaled fp16 only); 5: sixdgs_scorer_weights carries the composite layer w4k / b4k / m4k (k_proj folded into ray-MLP layer 4 on the key-cache path), sixdgs_select_begin / _sample_stats take h_n_tok (token packing of the select sweep); 4: the select path's slack derived from |q| |k| (sixdgs_key_planes_norm_max; q + d_key_norm_max arguments) and its ray-sharded form (sample_stats / prepare / topk_u, d_uk, allow_fewer), tile maxima of U (u_tile_max); 3: sixdgs_score_select + sixdgs_select_* stages (top-k without materialised logits); 2: plane-format scorer entry points, pass1/pass2, grid kNN, split-K, distance target */
 #define SIXDGS_E_BADARG (-1)
 #define SIXDGS_E_WORKSPACE (-2)
 #define SIXDGS_E_UNSUPPORTED (-3)
@@ -269,6 +269,15 @@ int sixdgs_im2col(const float* x, int64_t stride_b, int64_t stride_c, int64_t st
  * out = table256[value] (the caller's table carries the reference's true division); pixels a multiple of 4. */
 int sixdgs_u8_to_planar(const uint8_t* images, int batch, int64_t pixels, const float* table256, float* out, sixdgs_stream_t stream);
 
+/* a16 + the wrapper's transform pipeline for a batch of RGB images of one size (pose_estimation/test.py:69-73, backbone.py:52-77: uint8 / 255.0 -> Resize(256,
+ * bicubic, antialias) -> CenterCrop(224) -> Normalize) in one pass: images [batch][height][width][3] uint8 -> out [batch][3][out_size][out_size] fp32 =
+ * (crop(resize_aa(table256[value])) - mean3[c]) / std3[c].  The caller states the geometry the reference's transforms would use: the resized grid
+ * (resized_h, resized_w) and the crop's corner in it.  The arithmetic is the antialiased bicubic of the op it replaces (spans, a = -0.5 filter, tap-order sums, rows
+ * reduced along x first), with the x-reductions shared between the output rows of a band; mean3 / std3 are HOST arrays (read at the call).  SIXDGS_E_UNSUPPORTED for
+ * scales beyond 15 or windows that do not fit the kernel's LDS: the caller keeps PyTorch's kernels for those. */
+int sixdgs_image_prep(const uint8_t* images, int batch, int height, int width, const float* table256, int resized_h, int resized_w, int crop_top, int crop_left,
+                      int out_size, const float* mean3, const float* std3, float* out, sixdgs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Scorer, image side (per batch of query images)
  * replaces MultiHeadAttention.forward (our_multihead_attention.py:70-79, 4-12),
@@ -316,8 +325,8 @@ int sixdgs_score_pass2(const float* row_stats, const int32_t* d_n_tok, int batch
  * else: test.py:105-107).  Needs the scaled fp16 key planes of ALL r rays (sixdgs_ray_keys_ex, SIXDGS_MMA_F16X3) and those of a
  * ray SAMPLE (any r_sample <= r rays of the same scene, e.g. one ray in 16, through the same entry point).  score[r] =
  * sum_t e[t][r] / Z_t with e = exp(logit - ref_t), Z_t = sum_r e[t][r]:
- *   pre-pass    over the sample: ref_t = sample maximum, Z~_t = sample sum (so that f Z~_t ~ Z_t, f = r / r_sample).  Since round 6, for launches of two or more 256-token slots, with ONE of the
- *               three MFMA terms (h x h: logits to ~2^-11 |q||k| / sqrt(384); SIXDGS_PREPASS_TERMS=3 / 1 force three / one): these two only set the sweep's
+ *   pre-pass    over the sample: ref_t = sample maximum, Z~_t = sample sum (so that f Z~_t ~ Z_t, f = r / r_sample).  Since round 6 with ONE of the
+ *               three MFMA terms (h x h: logits to ~2^-11 |q||k| / sqrt(384); SIXDGS_PREPASS_TERMS=3 restores all three): these two only set the sweep's
  *               exponent offsets and scale -- g_t below is exact relative to WHATEVER Z~_t the sweep was given;
  *   main sweep  over all rays, one matrix-core pass, nothing of size T x R leaves the chip: U[r] = sum_t e[t][r] / (f Z~_t)
  *               (4 x 4 B per ray and image instead of 784 B of logits) and the EXACT g_t = Z_t / (f Z~_t);

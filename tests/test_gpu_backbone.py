@@ -278,6 +278,52 @@ def test_im2col_and_u8_to_planar_are_exact(ops):
     assert batch.permute(0, 3, 1, 2).is_contiguous()                      # what preprocess_batch hands to the resize: planar, no copy
 
 
+def test_image_prep_against_the_transform_pipeline_it_replaces(ops, monkeypatch):
+    """sixdgs_image_prep (uint8 -> table lookup -> antialiased bicubic Resize(256) -> CenterCrop(224) -> Normalize in one kernel, x-reductions shared between
+    the output rows of a band) against BackboneWrapper.transformations on the table's values -- PyTorch's upsample_gen2d_aa on the GPU and its separable CPU
+    implementation in fp64 -- over square, landscape, portrait, barely-downscaled and UPscaled queries, one image and a batch that takes the 8-row bands:
+    <= 5e-6 of the GPU op (a dozen ulps of values spanning [-2.2, 2.7]: the compiler's choice of fused multiply-adds in the weights), as close to fp64 as that op is; then the tokens of the product's image side with and without it."""
+    bb = importlib.import_module("6dgs_amd.backbone")
+    tp = importlib.import_module("6dgs_amd.test")
+    pkg = importlib.import_module("6dgs_amd")
+    wrapper = bb.BackboneWrapper("dino").cuda().eval()
+    w_cpu = bb.BackboneWrapper("dino", backbone=wrapper.image_preprocessing_net).double()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    lut = tp._u8_lut("cuda")
+    errs = []
+    for b, h, w in ((2, 800, 800), (1, 400, 400), (3, 480, 640), (2, 750, 500), (1, 260, 300), (2, 200, 180), (72, 300, 300)):
+        # smooth + noisy content: low-pass a random field so that neighbouring taps differ moderately, plus full-range noise on a third of the pixels
+        base = torch.rand(b, h // 8 + 2, w // 8 + 2, 3, generator=g)
+        up = torch.nn.functional.interpolate(base.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        noise = torch.rand(b, h, w, 3, generator=g)
+        img = torch.where(torch.rand(b, h, w, 1, generator=g) < 0.33, noise, up)
+        u8 = (img * 255).round().clamp(0, 255).to(torch.uint8).cuda()
+        out = ops.image_prep(u8, lut, bb.IMAGENET_DEFAULT_MEAN, bb.IMAGENET_DEFAULT_STD)
+        assert out is not None and out.shape == (b, 3, 224, 224), (b, h, w)
+        f32 = lut[u8.long()]
+        with torch.no_grad():
+            ref_gpu = wrapper.preprocess_batch(f32)
+            ref64 = w_cpu.transformations(f32[: min(b, 3)].double().cpu().permute(0, 3, 1, 2))
+        e_gpu = float((out - ref_gpu).abs().max())
+        e_64 = float((out[: min(b, 3)].double().cpu() - ref64).abs().max())
+        base_64 = float((ref_gpu[: min(b, 3)].double().cpu() - ref64).abs().max())          # what the op itself is off by
+        errs.append((b, h, w, e_gpu, e_64, base_64))
+    print("image_prep (batch, h, w, vs the GPU op, vs fp64, the GPU op vs fp64):", errs)
+    # (a barely-downscaled image -- 260 x 300, scale 1.016 -- is where PyTorch's own two implementations are 1e-4 apart; the kernel follows the GPU one)
+    assert all(e[3] <= 5e-6 and e[4] <= max(4e-6, 1.1 * e[5] + 4e-6) for e in errs), errs
+    assert ops.image_prep(torch.zeros(1, 256, 300, 3, dtype=torch.uint8, device="cuda"), lut, bb.IMAGENET_DEFAULT_MEAN, bb.IMAGENET_DEFAULT_STD) is None   # no resize: the op is skipped there
+    # the product's image side: same tokens and feature maps to 1e-5 of the largest token with the kernel and with PyTorch's kernels (SIXDGS_IMAGE_PREP=0)
+    idm = pkg.IdentificationModule("dino").cuda().eval()
+    imgs = [torch.randint(0, 256, (800, 800, 3), generator=g, dtype=torch.uint8).cuda() for _ in range(3)]
+    with torch.no_grad():
+        t1, f1 = tp.image_side_tokens(idm, imgs)
+        monkeypatch.setenv("SIXDGS_IMAGE_PREP", "0")
+        t0, f0 = tp.image_side_tokens(idm, imgs)
+        monkeypatch.delenv("SIXDGS_IMAGE_PREP")
+    a, c = (t1.feats if hasattr(t1, "feats") else t1), (t0.feats if hasattr(t0, "feats") else t0)
+    assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()) and float((f1 - f0).abs().max()) <= 1e-5 * float(f0.abs().max())
+
+
 @pytest.mark.parametrize("images", [1, 3])
 def test_fused_vit_blocks_equal_the_unfused_module(images, monkeypatch):
     """ViTS14.forward_features with the five-launch blocks (backbone.fused_blocks; every stage forced, and the default choice by row count) against the
