@@ -531,7 +531,7 @@ def main():
             try:
                 tj = json.load(open(args.traffic_json))
                 is_sel = "select" in path and not path.startswith("streamed")
-                sl = getattr(idm, "last_select_launches", None)
+                sl = out["config"].get("select_sweep_launches")      # (as recorded behind the timed steps: the secondary figure below it has run other batches since)
                 per_launch = (sl[0][1] if (is_sel and sl) else inflight)      # images the dominant kernel's launch scores: the select sweep's plan, or the two-pass workspace's share
                 if tj.get("rays") == R and tj.get("mode") == args.mode and tj.get("mma") == out["config"]["mma"] and tj.get("images_per_launch") == per_launch and tj.get("path", "two-pass") == ("select" if is_sel else "two-pass"):
                     traffic = tj.get("hbm_bytes_per_launch")
