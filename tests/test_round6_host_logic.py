@@ -72,3 +72,18 @@ def test_fused_vit_blocks_are_a_gpu_inference_path_only():
     with torch.no_grad():
         out = vit.forward_features(torch.zeros(1, 3, 224, 224))
     assert out["x_norm_patchtokens"].shape == (1, 256, 384)
+
+
+def test_image_prep_geometry_is_the_wrappers_resize_and_crop(ops):
+    """ops.image_prep_geometry states for sixdgs_image_prep what BackboneWrapper's Resize(256) + CenterCrop(224) do to an h x w image (backbone.py:52-77 as mirrored in
+    6dgs_amd/backbone.py): the resized grid and the crop's corner -- checked against the shapes and the content position those two functions produce on the CPU."""
+    bb = importlib.import_module("6dgs_amd.backbone")
+    for h, w in ((800, 800), (400, 400), (480, 640), (750, 500), (260, 300), (200, 180), (256, 300), (1080, 1920)):
+        nh, nw, top, left = ops.image_prep_geometry(h, w)
+        x = torch.zeros(1, 1, h, w)
+        r = bb._resize_short_side(x, 256, "bicubic")
+        assert tuple(r.shape[-2:]) == (nh, nw), (h, w)
+        ramp = torch.arange(nh * nw, dtype=torch.float32).view(1, 1, nh, nw)          # which resized-grid pixel lands at the crop's corner
+        c = bb._center_crop(ramp, 224)
+        assert tuple(c.shape[-2:]) == (224, 224) and int(c[0, 0, 0, 0]) == top * nw + left, (h, w)
+    assert ops.image_prep_enabled() in (True, False)
