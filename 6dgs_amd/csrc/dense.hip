@@ -346,6 +346,20 @@ __global__ void __launch_bounds__(512, 1) k_dense_planes(DenseArgs A, unsigned n
         }
       }
     }
+#ifdef SDG_FUSE_L1_PROBE
+    // Timing probe (developer build, profiles/r06_chain_l1_fused_probe.md): the MATRIX WORK a loader that recomputes h1 = ReLU(W1 x) would add to a layer-2 pass -- per
+    // slab of 32 h1 features 32 x 256 rays x 160 inputs x 3 terms = 240 MFMAs per workgroup, 30 per wave -- issued here on a zero weight fragment (the sums, hence the keys,
+    // are unchanged), for the 16-slab layer only.  Everything else such a loader needs (x streamed 16 x from L2, 64 more accumulators, the block scale of h1) is NOT in it.
+    if (NTM == 2 && NTN == 4 && ks == 16) {
+      f16x8_t z;
+#pragma unroll
+      for (int e_ = 0; e_ < 8; ++e_) z[e_] = (_Float16)0.f;
+      asm volatile("" : "+v"(z));
+      const f16x8_t bz = *reinterpret_cast<const f16x8_t*>(smem + buf * kWStage + (FP + wn * 32 * NTN + frow) * kPRow + fk);
+#pragma unroll
+      for (int i_ = 0; i_ < 30; ++i_) acc[i_ & 1][(i_ >> 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(z, bz, acc[i_ & 1][(i_ >> 1) & 3], 0, 0, 0);
+    }
+#endif
     SDG_ADVANCE()
     SDG_T(t1_)
     SDG_ACC(0, t0_, t1_)
